@@ -1,0 +1,245 @@
+"""ctypes binding of libcofactor_hip.so (include/cofactor_hip.h) for tests and bench.py.
+
+Thin by design: every call goes straight through the C ABI; torch is only used by callers for
+device memory (the binding takes raw device pointers via ``tensor.data_ptr()``).  There is no
+fallback of any kind: if the library is missing or there is no GPU, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcofactor_hip.so")
+
+TRIPLE, NB = 0, 1
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)
+
+# every symbol include/cofactor_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "cofactor_last_error", "cofactor_abi_version",
+    "cofactor_ctx_create", "cofactor_ctx_destroy", "cofactor_ctx_synchronize", "cofactor_ctx_stream",
+    "cofactor_agg_create", "cofactor_agg_destroy", "cofactor_agg_reset",
+    "cofactor_agg_update_device", "cofactor_agg_update_host", "cofactor_agg_update_triples",
+    "cofactor_agg_combine", "cofactor_agg_finalize",
+    "cofactor_dense_len", "cofactor_agg_export_dense_device", "cofactor_agg_import_dense_device",
+    "cofactor_lift_host", "cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub",
+    "cofactor_blob_len",
+]
+
+_lib = None
+
+
+class CofactorError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("cofactor status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CofactorError(-1, "libcofactor_hip.so not built (run __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        vp, pp, u64 = C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64
+        pu64 = C.POINTER(C.c_uint64)
+        L.cofactor_last_error.restype = C.c_char_p
+        L.cofactor_ctx_create.argtypes = [C.c_int, pp]
+        L.cofactor_ctx_destroy.argtypes = [vp]
+        L.cofactor_ctx_destroy.restype = None
+        L.cofactor_ctx_synchronize.argtypes = [vp]
+        L.cofactor_ctx_stream.argtypes = [vp]
+        L.cofactor_ctx_stream.restype = vp
+        L.cofactor_agg_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, pp]
+        L.cofactor_agg_destroy.argtypes = [vp]
+        L.cofactor_agg_destroy.restype = None
+        L.cofactor_agg_reset.argtypes = [vp]
+        L.cofactor_agg_update_device.argtypes = [vp, pp, pp, u64]
+        L.cofactor_agg_update_host.argtypes = [vp, pp, pp, pp, pp, vp, u64]
+        L.cofactor_agg_update_triples.argtypes = [vp, vp, vp, u64]
+        L.cofactor_agg_combine.argtypes = [vp, vp]
+        L.cofactor_agg_finalize.argtypes = [vp, vp, u64, pu64]
+        L.cofactor_dense_len.argtypes = [C.c_int, C.c_int]
+        L.cofactor_dense_len.restype = u64
+        L.cofactor_agg_export_dense_device.argtypes = [vp, vp]
+        L.cofactor_agg_import_dense_device.argtypes = [vp, vp]
+        L.cofactor_lift_host.argtypes = [pp, C.c_int, pp, C.c_int, u64, C.c_int, vp, u64, pu64, vp]
+        for f in ("cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub"):
+            getattr(L, f).argtypes = [vp, vp, vp, u64, pu64]
+        L.cofactor_blob_len.argtypes = [vp]
+        L.cofactor_blob_len.restype = u64
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != OK:
+        raise CofactorError(status, lib().cofactor_last_error().decode())
+
+
+def _ptr_array(ptrs):
+    return (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+
+
+def _two_call(fn, *args):
+    """The header's two-call protocol: size query, then fill."""
+    need = C.c_uint64(0)
+    _check(fn(*args, None, 0, C.byref(need)))
+    out = np.empty(need.value, dtype=np.float64)
+    _check(fn(*args, out.ctypes.data, out.size, C.byref(need)))
+    return out
+
+
+class Context:
+    """One GPU (cofactor_ctx)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib().cofactor_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cofactor_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def synchronize(self):
+        _check(lib().cofactor_ctx_synchronize(self._h))
+
+    @property
+    def stream(self):
+        """Raw hipStream_t of the context (an int)."""
+        return lib().cofactor_ctx_stream(self._h)
+
+    def aggregate(self, n_num, n_cat, kind=TRIPLE):
+        return Aggregate(self, n_num, n_cat, kind)
+
+
+class Aggregate:
+    """One aggregate state (cofactor_agg): what a Triple::SumState is in the reference."""
+
+    def __init__(self, ctx, n_num, n_cat, kind=TRIPLE):
+        h = C.c_void_p()
+        _check(lib().cofactor_agg_create(ctx._h, n_num, n_cat, kind, C.byref(h)))
+        self._h, self.ctx, self.n, self.m, self.kind = h, ctx, n_num, n_cat, kind
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().cofactor_agg_destroy(self._h)
+        self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().cofactor_agg_reset(self._h))
+
+    def update_device_ptrs(self, num_ptrs, cat_ptrs, rows):
+        """Raw device pointers (ints), e.g. tensor.data_ptr()."""
+        assert len(num_ptrs) == self.n and len(cat_ptrs) == self.m
+        _check(lib().cofactor_agg_update_device(self._h, _ptr_array(num_ptrs), _ptr_array(cat_ptrs),
+                                                rows))
+
+    def update_device(self, num_tensors, cat_tensors):
+        """Columns as 1-D contiguous torch tensors on this context's GPU (float32 / int32).
+        The caller makes sure they are complete (torch.cuda.synchronize() or stream order)."""
+        rows = None
+        for t, want in [(t, "torch.float32") for t in num_tensors] + \
+                       [(t, "torch.int32") for t in cat_tensors]:
+            assert str(t.dtype) == want and t.is_contiguous() and t.dim() == 1 and t.is_cuda, \
+                "columns must be 1-D contiguous device tensors of float32 / int32"
+            rows = t.numel() if rows is None else rows
+            assert t.numel() == rows
+        self.update_device_ptrs([t.data_ptr() for t in num_tensors],
+                                [t.data_ptr() for t in cat_tensors], rows or 0)
+
+    def update_host(self, num_cols, cat_cols, num_sel=None, cat_sel=None, row_idx=None, rows=None):
+        """One DataChunk of host columns (numpy), optional per-column selection vectors and the
+        list of chunk rows that belong to this state (see the header)."""
+        num = [np.ascontiguousarray(c, dtype=np.float32) for c in num_cols]
+        cat = [np.ascontiguousarray(c, dtype=np.int32) for c in cat_cols]
+        assert len(num) == self.n and len(cat) == self.m
+        keep = [num, cat]
+
+        def sel_array(sels, k):
+            if sels is None:
+                return None
+            arrs = [None if s is None else np.ascontiguousarray(s, dtype=np.uint32) for s in sels]
+            keep.append(arrs)
+            return _ptr_array([0 if a is None else a.ctypes.data for a in arrs]) if k else None
+
+        ns, cs = sel_array(num_sel, self.n), sel_array(cat_sel, self.m)
+        ri = None if row_idx is None else np.ascontiguousarray(row_idx, dtype=np.uint32)
+        if rows is None:
+            if ri is not None:
+                rows = len(ri)
+            else:
+                first = (num + cat)[0]
+                firstsel = (list(num_sel or []) + list(cat_sel or []))
+                rows = len(firstsel[0]) if firstsel and firstsel[0] is not None else len(first)
+        _check(lib().cofactor_agg_update_host(
+            self._h, _ptr_array([c.ctypes.data for c in num]), _ptr_array([c.ctypes.data for c in cat]),
+            ns, cs, None if ri is None else ri.ctypes.data, rows))
+
+    def update_triples(self, blobs):
+        offs = np.zeros(len(blobs) + 1, dtype=np.uint64)
+        for i, b in enumerate(blobs):
+            offs[i + 1] = offs[i] + len(b)
+        flat = np.ascontiguousarray(np.concatenate(blobs) if blobs else np.zeros(0), dtype=np.float64)
+        _check(lib().cofactor_agg_update_triples(self._h, flat.ctypes.data, offs.ctypes.data, len(blobs)))
+
+    def combine(self, other):
+        _check(lib().cofactor_agg_combine(self._h, other._h))
+
+    def finalize(self):
+        return _two_call(lib().cofactor_agg_finalize, self._h)
+
+    def dense_len(self):
+        return lib().cofactor_dense_len(self.n, self.kind)
+
+    def export_dense_device(self, ptr):
+        _check(lib().cofactor_agg_export_dense_device(self._h, ptr))
+
+    def import_dense_device(self, ptr):
+        _check(lib().cofactor_agg_import_dense_device(self._h, ptr))
+
+
+def lift_host(num_cols, cat_cols, kind=TRIPLE):
+    """to_cofactor / to_nb_agg: list of one blob per row."""
+    num = [np.ascontiguousarray(c, dtype=np.float32) for c in num_cols]
+    cat = [np.ascontiguousarray(c, dtype=np.int32) for c in cat_cols]
+    rows = len(num[0]) if num else (len(cat[0]) if cat else 0)
+    offs = np.zeros(rows + 1, dtype=np.uint64)
+    np_, cp_ = _ptr_array([c.ctypes.data for c in num]), _ptr_array([c.ctypes.data for c in cat])
+    need = C.c_uint64(0)
+    _check(lib().cofactor_lift_host(np_, len(num), cp_, len(cat), rows, kind, None, 0, C.byref(need), None))
+    out = np.empty(need.value, dtype=np.float64)
+    _check(lib().cofactor_lift_host(np_, len(num), cp_, len(cat), rows, kind, out.ctypes.data, out.size,
+                                    C.byref(need), offs.ctypes.data))
+    return [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(rows)]
+
+
+def _binary(fn, a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return _two_call(fn, a.ctypes.data, b.ctypes.data)
+
+
+def multiply(a, b):
+    return _binary(lib().cofactor_triple_multiply, a, b)
+
+
+def add(a, b):
+    return _binary(lib().cofactor_triple_add, a, b)
+
+
+def sub(a, b):
+    return _binary(lib().cofactor_triple_sub, a, b)
+
+
+def blob_len(blob):
+    b = np.ascontiguousarray(blob, dtype=np.float64)
+    return lib().cofactor_blob_len(b.ctypes.data)

@@ -1,0 +1,656 @@
+// C ABI of libcofactor_hip.so (include/cofactor_hip.h): contexts, aggregate states, the update /
+// combine / finalize life cycle of the reference's aggregates, and the scalar ring ops.
+// There is no CPU fallback for the aggregate: without a GPU cofactor_ctx_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device.hpp"
+#include "triple.hpp"
+
+using namespace cofactor;
+
+namespace {
+
+thread_local std::string g_err;
+
+cofactor_status fail(cofactor_status st, const std::string &msg) {
+  g_err = msg;
+  return st;
+}
+cofactor_status hip_fail(hipError_t e, const char *what) {
+  return fail(COFACTOR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                        \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);        \
+  } while (0)
+
+long env_long(const char *name, long dflt) {
+  const char *v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  char *end = nullptr;
+  long x = std::strtol(v, &end, 10);
+  return (end && *end == 0 && x > 0) ? x : dflt;
+}
+
+int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+struct cofactor_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int cus = 0;
+  int gram_grid = 0;            // workgroups of the Gram kernel
+  int cat_grid = 0;             // workgroups of the categorical kernel
+  size_t lds_budget = 0;        // bytes of LDS one categorical workgroup may claim
+  double *partials = nullptr;   // gram_grid * GRAM_ACC_LEN doubles
+};
+
+struct cofactor_agg {
+  cofactor_ctx *ctx = nullptr;
+  int n = 0, m = 0, kind = 0;
+  HostTriple host;              // everything merged in on the host (combine, lifted triples, import)
+  double dev_rows = 0;          // rows whose contributions sit in the device tables
+  double *d_acc = nullptr;      // dense accumulator image (GRAM_ACC_LEN doubles)
+  // categorical device state
+  bool cat_ready = false;
+  bool cat_check_pending = false;
+  CatLayout L{};
+  CatDevice D{};
+  // host staging for update_host (pinned) and its device mirror
+  uint64_t stage_cap = 0, stage_rows = 0;
+  float *h_num = nullptr;
+  int32_t *h_cat = nullptr;
+  float *d_num = nullptr;
+  int32_t *d_cat = nullptr;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void cat_free(CatDevice &D) {
+  (void)hipFree(D.ht_slot); (void)hipFree(D.ht_code); (void)hipFree(D.nkeys); (void)hipFree(D.flags);
+  (void)hipFree(D.cnt); (void)hipFree(D.s); (void)hipFree(D.p);
+  D = CatDevice{};
+}
+
+// Fills offsets / totals of L from its n, m, kind, ht_cap[], kc[].  False if a table would
+// overflow the 31-bit indices the kernels use.
+bool cat_finish_layout(CatLayout &L) {
+  uint64_t slots = 0, cnt = 0, s = 0, p = 0;
+  for (int c = 0; c < L.m; c++) {
+    L.ht_off[c] = (int)slots; slots += (uint64_t)L.ht_cap[c];
+    L.cnt_off[c] = (int)cnt;  cnt += (uint64_t)L.kc[c];
+    L.s_off[c] = (int)s;      s += (uint64_t)L.kc[c] * (uint64_t)L.n;
+    if (slots > (1ull << 30) || cnt > (1ull << 30) || s > (1ull << 30)) return false;
+  }
+  int q = 0;
+  for (int c1 = 0; c1 < L.m; c1++)
+    for (int c2 = c1; c2 < L.m; c2++, q++) {
+      L.p_off[q] = (int)p;
+      p += (uint64_t)L.kc[c1] * (uint64_t)L.kc[c2];
+      if (p > (1ull << 30)) return false;
+    }
+  L.n_slots = (int)slots; L.n_cnt = (int)cnt;
+  L.n_s = L.kind == 0 ? (int)s : 0;
+  L.n_p = L.kind == 0 ? (int)p : 0;
+  return true;
+}
+
+cofactor_status cat_alloc(const CatLayout &L, CatDevice &D, bool fresh_counters, hipStream_t st) {
+  D = CatDevice{};
+  HIP_TRY(hipMalloc((void **)&D.ht_slot, sizeof(unsigned long long) * std::max(1, L.n_slots)));
+  HIP_TRY(hipMalloc((void **)&D.ht_code, sizeof(int32_t) * std::max(1, L.n_slots)));
+  HIP_TRY(hipMalloc((void **)&D.cnt, sizeof(unsigned long long) * std::max(1, L.n_cnt)));
+  HIP_TRY(hipMalloc((void **)&D.s, sizeof(double) * std::max(1, L.n_s)));
+  HIP_TRY(hipMalloc((void **)&D.p, sizeof(unsigned long long) * std::max(1, L.n_p)));
+  HIP_TRY(hipMemsetAsync(D.ht_slot, 0, sizeof(unsigned long long) * std::max(1, L.n_slots), st));
+  HIP_TRY(hipMemsetAsync(D.ht_code, 0xFF, sizeof(int32_t) * std::max(1, L.n_slots), st));
+  HIP_TRY(hipMemsetAsync(D.cnt, 0, sizeof(unsigned long long) * std::max(1, L.n_cnt), st));
+  HIP_TRY(hipMemsetAsync(D.s, 0, sizeof(double) * std::max(1, L.n_s), st));
+  HIP_TRY(hipMemsetAsync(D.p, 0, sizeof(unsigned long long) * std::max(1, L.n_p), st));
+  if (fresh_counters) {
+    HIP_TRY(hipMalloc((void **)&D.nkeys, sizeof(int32_t) * COFACTOR_MAX_CAT));
+    HIP_TRY(hipMalloc((void **)&D.flags, sizeof(int32_t) * 4));
+    HIP_TRY(hipMemsetAsync(D.nkeys, 0, sizeof(int32_t) * COFACTOR_MAX_CAT, st));
+    HIP_TRY(hipMemsetAsync(D.flags, 0, sizeof(int32_t) * 4, st));
+  }
+  return COFACTOR_OK;
+}
+
+// Replaces the aggregate's dictionary and/or tables by ones with layout Lnew, carrying over
+// every key, code and accumulated value.
+cofactor_status cat_regrow(cofactor_agg *a, const CatLayout &Lnew) {
+  hipStream_t st = a->ctx->stream;
+  CatDevice Dn;
+  cofactor_status s = cat_alloc(Lnew, Dn, false, st);
+  if (s != COFACTOR_OK) return s;
+  Dn.nkeys = a->D.nkeys;
+  Dn.flags = a->D.flags;
+  HIP_TRY(launch_cat_rehash(a->L, a->D, Lnew, Dn, st));
+  HIP_TRY(launch_cat_relayout(a->L, a->D, Lnew, Dn, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  CatDevice old = a->D;
+  old.nkeys = nullptr; old.flags = nullptr;     // kept
+  cat_free(old);
+  a->D = Dn;
+  a->L = Lnew;
+  return COFACTOR_OK;
+}
+
+cofactor_status cat_prepare(cofactor_agg *a) {
+  if (a->cat_ready || a->m == 0) return COFACTOR_OK;
+  CatLayout &L = a->L;
+  L = CatLayout{};
+  L.n = a->n; L.m = a->m; L.kind = a->kind;
+  for (int c = 0; c < a->m; c++) { L.ht_cap[c] = 64; L.kc[c] = 16; }
+  if (!cat_finish_layout(L)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical layout overflow");
+  cofactor_status s = cat_alloc(L, a->D, true, a->ctx->stream);
+  if (s != COFACTOR_OK) return s;
+  a->cat_ready = true;
+  return COFACTOR_OK;
+}
+
+// The categorical half of one device update.
+cofactor_status cat_update(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows) {
+  cofactor_status s = cat_prepare(a);
+  if (s != COFACTOR_OK) return s;
+  hipStream_t st = a->ctx->stream;
+  int32_t counters[COFACTOR_MAX_CAT + 4];
+  for (int attempt = 0;; attempt++) {
+    HIP_TRY(hipMemsetAsync(a->D.flags, 0, sizeof(int32_t), st));   // [0] only; [1] is sticky
+    HIP_TRY(launch_cat_insert(cat, rows, a->L, a->D, st));
+    HIP_TRY(hipMemcpyAsync(counters + COFACTOR_MAX_CAT, a->D.flags, sizeof(int32_t) * 4,
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (counters[COFACTOR_MAX_CAT] == 0) break;
+    if (attempt > 24) return fail(COFACTOR_ERR_UNSUPPORTED, "dictionary growth did not converge");
+    CatLayout Ln = a->L;                          // a dictionary ran full: quadruple all of them
+    for (int c = 0; c < a->m; c++) {
+      if (Ln.ht_cap[c] >= (1 << 28)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical column has too many distinct keys");
+      Ln.ht_cap[c] *= 4;
+    }
+    if (!cat_finish_layout(Ln)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical dictionaries too large");
+    s = cat_regrow(a, Ln);
+    if (s != COFACTOR_OK) return s;
+  }
+  HIP_TRY(launch_cat_assign_codes(a->L, a->D, st));
+  HIP_TRY(hipMemcpyAsync(counters, a->D.nkeys, sizeof(int32_t) * COFACTOR_MAX_CAT,
+                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  bool grow = false;
+  CatLayout Ln = a->L;
+  for (int c = 0; c < a->m; c++) {
+    if (counters[c] > Ln.kc[c]) { Ln.kc[c] = next_pow2(counters[c]); grow = true; }
+    while (counters[c] * 2 > Ln.ht_cap[c]) { Ln.ht_cap[c] *= 2; grow = true; }  // load factor <= 1/2
+  }
+  if (grow) {
+    if (!cat_finish_layout(Ln))
+      return fail(COFACTOR_ERR_UNSUPPORTED,
+                  "categorical cardinalities too high for dense code-indexed pair tables "
+                  "(sparse pair tables are not implemented yet)");
+    s = cat_regrow(a, Ln);
+    if (s != COFACTOR_OK) return s;
+  }
+  const size_t lds = cat_lds_bytes(a->L);
+  const bool lds_tables = lds <= a->ctx->lds_budget;
+  HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, lds_tables, a->ctx->cat_grid, st));
+  a->cat_check_pending = true;                    // flags[1] is looked at by the next snapshot
+  return COFACTOR_OK;
+}
+
+cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const CatCols &cat,
+                                   uint64_t rows) {
+  if (rows == 0) return COFACTOR_OK;
+  cofactor_ctx *ctx = a->ctx;
+  if (a->n > 0)
+    HIP_TRY(launch_gram(num, a->n, rows, ctx->gram_grid, ctx->partials, a->d_acc, ctx->stream));
+  if (a->m > 0) {
+    cofactor_status s = cat_update(a, num, cat, rows);
+    if (s != COFACTOR_OK) return s;
+  }
+  a->dev_rows += (double)rows;
+  return COFACTOR_OK;
+}
+
+cofactor_status stage_flush(cofactor_agg *a) {
+  if (a->stage_rows == 0) return COFACTOR_OK;
+  hipStream_t st = a->ctx->stream;
+  const uint64_t cap = a->stage_cap, rows = a->stage_rows;
+  NumCols num{};
+  CatCols cat{};
+  for (int k = 0; k < a->n; k++) {
+    HIP_TRY(hipMemcpyAsync(a->d_num + k * cap, a->h_num + k * cap, rows * sizeof(float),
+                           hipMemcpyHostToDevice, st));
+    num.p[k] = a->d_num + k * cap;
+  }
+  for (int c = 0; c < a->m; c++) {
+    HIP_TRY(hipMemcpyAsync(a->d_cat + c * cap, a->h_cat + c * cap, rows * sizeof(int32_t),
+                           hipMemcpyHostToDevice, st));
+    cat.p[c] = a->d_cat + c * cap;
+  }
+  cofactor_status s = update_device_impl(a, num, cat, rows);
+  if (s != COFACTOR_OK) return s;
+  HIP_TRY(hipStreamSynchronize(st));              // the pinned buffer is refilled next
+  a->stage_rows = 0;
+  return COFACTOR_OK;
+}
+
+// Device tables + host accumulator -> one HostTriple (synchronises).
+cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = false) {
+  DeviceGuard guard(a->ctx->device);
+  cofactor_status s = stage_flush(a);
+  if (s != COFACTOR_OK) return s;
+  hipStream_t st = a->ctx->stream;
+  out.shape(a->kind, a->n, a->m);
+  out.N = a->dev_rows;
+  std::vector<double> acc(GRAM_ACC_LEN, 0.0);
+  if (a->n > 0 && a->dev_rows > 0) {
+    HIP_TRY(hipMemcpyAsync(acc.data(), a->d_acc, sizeof(double) * GRAM_ACC_LEN, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int c = 0; c < a->n; c++) out.lin[c] = acc[gram_lin_pos(c, a->n)];
+    if (a->kind == COFACTOR_NB) {
+      for (int j = 0; j < a->n; j++) out.quad[j] = acc[gram_quad_pos(j, j, a->n)];
+    } else {
+      size_t q = 0;
+      for (int j = 0; j < a->n; j++)
+        for (int k = j; k < a->n; k++) out.quad[q++] = acc[gram_quad_pos(j, k, a->n)];
+    }
+  }
+  if (!dense_only && a->m > 0 && a->cat_ready && a->dev_rows > 0) {
+    const CatLayout &L = a->L;
+    std::vector<unsigned long long> slot(L.n_slots), cnt(L.n_cnt), p(std::max(1, L.n_p));
+    std::vector<int32_t> code(L.n_slots);
+    std::vector<double> sums(std::max(1, L.n_s));
+    HIP_TRY(hipMemcpyAsync(slot.data(), a->D.ht_slot, sizeof(unsigned long long) * L.n_slots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(code.data(), a->D.ht_code, sizeof(int32_t) * L.n_slots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), a->D.cnt, sizeof(unsigned long long) * L.n_cnt, hipMemcpyDeviceToHost, st));
+    if (L.n_s) HIP_TRY(hipMemcpyAsync(sums.data(), a->D.s, sizeof(double) * L.n_s, hipMemcpyDeviceToHost, st));
+    if (L.n_p) HIP_TRY(hipMemcpyAsync(p.data(), a->D.p, sizeof(unsigned long long) * L.n_p, hipMemcpyDeviceToHost, st));
+    int32_t flags[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, a->D.flags, sizeof(flags), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (flags[1]) return fail(COFACTOR_ERR_HIP, "internal error: a row met a key missing from its dictionary");
+    a->cat_check_pending = false;
+    std::vector<std::vector<int32_t>> key_of(a->m);
+    std::vector<std::vector<char>> live(a->m);
+    for (int c = 0; c < a->m; c++) {
+      key_of[c].assign(L.kc[c], 0);
+      live[c].assign(L.kc[c], 0);
+      for (int sidx = 0; sidx < L.ht_cap[c]; sidx++) {
+        const unsigned long long v = slot[L.ht_off[c] + sidx];
+        const int cd = code[L.ht_off[c] + sidx];
+        if (v == 0ull || cd < 0 || cd >= L.kc[c]) continue;
+        const unsigned long long rows_of_key = cnt[L.cnt_off[c] + cd];
+        if (rows_of_key == 0) continue;           // key known to the dictionary, not to this state
+        const int32_t key = (int32_t)(unsigned)(v & 0xffffffffull);
+        key_of[c][cd] = key;
+        live[c][cd] = 1;
+        auto &vals = out.col[c][key];
+        vals.assign(a->kind ? 1 : (size_t)a->n + 1, 0.0);
+        vals[0] = (double)rows_of_key;
+        if (!a->kind)
+          for (int k = 0; k < a->n; k++) vals[k + 1] = sums[L.s_off[c] + (size_t)cd * a->n + k];
+      }
+    }
+    if (!a->kind) {
+      int q = 0;
+      for (int c1 = 0; c1 < a->m; c1++)
+        for (int c2 = c1; c2 < a->m; c2++, q++)
+          for (int k1 = 0; k1 < L.kc[c1]; k1++) {
+            if (!live[c1][k1]) continue;
+            for (int k2 = 0; k2 < L.kc[c2]; k2++) {
+              const unsigned long long v = p[L.p_off[q] + (size_t)k1 * L.kc[c2] + k2];
+              if (v) out.pair[q][{key_of[c1][k1], key_of[c2][k2]}] = (double)v;
+            }
+          }
+    }
+  }
+  if (dense_only) {
+    out.N += a->host.N;
+    for (int k = 0; k < a->n; k++) out.lin[k] += a->host.lin[k];
+    for (size_t k = 0; k < out.quad.size(); k++) out.quad[k] += a->host.quad[k];
+    return COFACTOR_OK;
+  }
+  std::string err;
+  if (!out.add(a->host, err)) return fail(COFACTOR_ERR_INVALID, err);
+  return COFACTOR_OK;
+}
+
+cofactor_status emit_blob(const std::vector<double> &blob, double *out, uint64_t cap, uint64_t *needed) {
+  if (needed) *needed = blob.size();
+  if (!out) return COFACTOR_OK;
+  if (cap < blob.size()) return fail(COFACTOR_ERR_CAPACITY, "output buffer too small");
+  std::memcpy(out, blob.data(), blob.size() * sizeof(double));
+  return COFACTOR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cofactor_last_error(void) { return g_err.c_str(); }
+int cofactor_abi_version(void) { return COFACTOR_ABI_VERSION; }
+
+cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
+  if (!out) return fail(COFACTOR_ERR_INVALID, "out is null");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(COFACTOR_ERR_NO_DEVICE, std::string("no HIP device available (") +
+                                            (e != hipSuccess ? hipGetErrorString(e) : "0 devices") +
+                                            "); libcofactor_hip has no CPU fallback");
+  if (device < 0 || device >= count) return fail(COFACTOR_ERR_NO_DEVICE, "device index out of range");
+  DeviceGuard guard(device);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  auto ctx = std::make_unique<cofactor_ctx>();
+  ctx->device = device;
+  ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->gram_grid = (int)env_long("COFACTOR_GRAM_WGS_PER_CU", 4) * ctx->cus;
+  ctx->cat_grid = (int)env_long("COFACTOR_CAT_WGS_PER_CU", 2) * ctx->cus;
+  ctx->lds_budget = (size_t)env_long("COFACTOR_CAT_LDS_BYTES", 150 * 1024);
+  if (ctx->lds_budget > prop.sharedMemPerBlock && prop.sharedMemPerBlock > 0)
+    ctx->lds_budget = prop.sharedMemPerBlock;
+  HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)ctx->gram_grid * GRAM_ACC_LEN));
+  *out = ctx.release();
+  return COFACTOR_OK;
+}
+
+void cofactor_ctx_destroy(cofactor_ctx *ctx) {
+  if (!ctx) return;
+  DeviceGuard guard(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->partials);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+cofactor_status cofactor_ctx_synchronize(cofactor_ctx *ctx) {
+  if (!ctx) return fail(COFACTOR_ERR_INVALID, "ctx is null");
+  DeviceGuard guard(ctx->device);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return COFACTOR_OK;
+}
+
+void *cofactor_ctx_stream(cofactor_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cofactor_kind kind,
+                                    cofactor_agg **out) {
+  if (!ctx || !out) return fail(COFACTOR_ERR_INVALID, "ctx/out is null");
+  *out = nullptr;
+  if (n_num < 0 || n_num > COFACTOR_MAX_NUM || n_cat < 0 || n_cat > COFACTOR_MAX_CAT)
+    return fail(COFACTOR_ERR_INVALID, "column counts must be in 0..20");
+  if (kind != COFACTOR_TRIPLE && kind != COFACTOR_NB) return fail(COFACTOR_ERR_INVALID, "unknown kind");
+  DeviceGuard guard(ctx->device);
+  auto a = std::make_unique<cofactor_agg>();
+  a->ctx = ctx; a->n = n_num; a->m = n_cat; a->kind = (int)kind;
+  a->host.shape(a->kind, a->n, a->m);
+  HIP_TRY(hipMalloc((void **)&a->d_acc, sizeof(double) * GRAM_ACC_LEN));
+  HIP_TRY(hipMemsetAsync(a->d_acc, 0, sizeof(double) * GRAM_ACC_LEN, ctx->stream));
+  *out = a.release();
+  return COFACTOR_OK;
+}
+
+void cofactor_agg_destroy(cofactor_agg *a) {
+  if (!a) return;
+  DeviceGuard guard(a->ctx->device);
+  (void)hipStreamSynchronize(a->ctx->stream);
+  (void)hipFree(a->d_acc);
+  if (a->cat_ready) cat_free(a->D);
+  if (a->h_num) (void)hipHostFree(a->h_num);
+  if (a->h_cat) (void)hipHostFree(a->h_cat);
+  (void)hipFree(a->d_num);
+  (void)hipFree(a->d_cat);
+  delete a;
+}
+
+cofactor_status cofactor_agg_reset(cofactor_agg *a) {
+  if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  DeviceGuard guard(a->ctx->device);
+  hipStream_t st = a->ctx->stream;
+  a->host.clear();
+  a->dev_rows = 0;
+  a->stage_rows = 0;
+  HIP_TRY(hipMemsetAsync(a->d_acc, 0, sizeof(double) * GRAM_ACC_LEN, st));
+  if (a->cat_ready) {
+    HIP_TRY(hipMemsetAsync(a->D.cnt, 0, sizeof(unsigned long long) * std::max(1, a->L.n_cnt), st));
+    HIP_TRY(hipMemsetAsync(a->D.s, 0, sizeof(double) * std::max(1, a->L.n_s), st));
+    HIP_TRY(hipMemsetAsync(a->D.p, 0, sizeof(unsigned long long) * std::max(1, a->L.n_p), st));
+  }
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_update_device(cofactor_agg *a, const float *const *d_num,
+                                           const int32_t *const *d_cat, uint64_t rows) {
+  if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  if ((a->n > 0 && !d_num) || (a->m > 0 && !d_cat)) return fail(COFACTOR_ERR_INVALID, "column array is null");
+  NumCols num{};
+  CatCols cat{};
+  for (int k = 0; k < a->n; k++) {
+    if (!d_num[k] && rows) return fail(COFACTOR_ERR_INVALID, "numeric column pointer is null");
+    if (reinterpret_cast<uintptr_t>(d_num[k]) & 3) return fail(COFACTOR_ERR_INVALID, "numeric column is not 4-byte aligned");
+    num.p[k] = d_num[k];
+  }
+  for (int c = 0; c < a->m; c++) {
+    if (!d_cat[c] && rows) return fail(COFACTOR_ERR_INVALID, "categorical column pointer is null");
+    if (reinterpret_cast<uintptr_t>(d_cat[c]) & 3) return fail(COFACTOR_ERR_INVALID, "categorical column is not 4-byte aligned");
+    cat.p[c] = d_cat[c];
+  }
+  DeviceGuard guard(a->ctx->device);
+  cofactor_status s = stage_flush(a);             // keep row order: staged host rows first
+  if (s != COFACTOR_OK) return s;
+  return update_device_impl(a, num, cat, rows);
+}
+
+cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *num,
+                                         const int32_t *const *cat, const uint32_t *const *num_sel,
+                                         const uint32_t *const *cat_sel, const uint32_t *row_idx,
+                                         uint64_t rows) {
+  if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  if ((a->n > 0 && !num) || (a->m > 0 && !cat)) return fail(COFACTOR_ERR_INVALID, "column array is null");
+  if (rows == 0) return COFACTOR_OK;
+  DeviceGuard guard(a->ctx->device);
+  if (!a->stage_cap) {
+    a->stage_cap = (uint64_t)env_long("COFACTOR_STAGE_ROWS", 1 << 18);
+    if (a->n) {
+      HIP_TRY(hipHostMalloc((void **)&a->h_num, sizeof(float) * a->n * a->stage_cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void **)&a->d_num, sizeof(float) * a->n * a->stage_cap));
+    }
+    if (a->m) {
+      HIP_TRY(hipHostMalloc((void **)&a->h_cat, sizeof(int32_t) * a->m * a->stage_cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void **)&a->d_cat, sizeof(int32_t) * a->m * a->stage_cap));
+    }
+  }
+  uint64_t done = 0;
+  while (done < rows) {
+    const uint64_t take = std::min(rows - done, a->stage_cap - a->stage_rows);
+    for (int k = 0; k < a->n; k++) {
+      float *dst = a->h_num + k * a->stage_cap + a->stage_rows;
+      const float *src = num[k];
+      const uint32_t *sel = num_sel ? num_sel[k] : nullptr;
+      if (!sel && !row_idx) std::memcpy(dst, src + done, take * sizeof(float));
+      else
+        for (uint64_t i = 0; i < take; i++) {
+          const uint64_t r = row_idx ? row_idx[done + i] : done + i;
+          dst[i] = src[sel ? sel[r] : r];
+        }
+    }
+    for (int c = 0; c < a->m; c++) {
+      int32_t *dst = a->h_cat + c * a->stage_cap + a->stage_rows;
+      const int32_t *src = cat[c];
+      const uint32_t *sel = cat_sel ? cat_sel[c] : nullptr;
+      if (!sel && !row_idx) std::memcpy(dst, src + done, take * sizeof(int32_t));
+      else
+        for (uint64_t i = 0; i < take; i++) {
+          const uint64_t r = row_idx ? row_idx[done + i] : done + i;
+          dst[i] = src[sel ? sel[r] : r];
+        }
+    }
+    a->stage_rows += take;
+    done += take;
+    if (a->stage_rows == a->stage_cap) {
+      cofactor_status s = stage_flush(a);
+      if (s != COFACTOR_OK) return s;
+    }
+  }
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_update_triples(cofactor_agg *a, const double *blobs,
+                                            const uint64_t *offsets, uint64_t count) {
+  if (!a || (count && (!blobs || !offsets))) return fail(COFACTOR_ERR_INVALID, "null argument");
+  ListTriple t;
+  std::string err;
+  for (uint64_t i = 0; i < count; i++) {
+    if (!blob_decode(blobs + offsets[i], t, err)) return fail(COFACTOR_ERR_INVALID, err);
+    if (!a->host.add_list(t, err)) return fail(COFACTOR_ERR_INVALID, err);
+  }
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_combine(cofactor_agg *dst, cofactor_agg *src) {
+  if (!dst || !src) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (dst == src) return fail(COFACTOR_ERR_INVALID, "combine of a state with itself");
+  if (dst->n != src->n || dst->m != src->m || dst->kind != src->kind)
+    return fail(COFACTOR_ERR_INVALID, "combine: state shapes differ");
+  HostTriple snap;
+  cofactor_status s = snapshot(src, snap);
+  if (s != COFACTOR_OK) return s;
+  std::string err;
+  if (!dst->host.add(snap, err)) return fail(COFACTOR_ERR_INVALID, err);
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap, uint64_t *needed) {
+  if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  HostTriple snap;
+  cofactor_status s = snapshot(a, snap);
+  if (s != COFACTOR_OK) return s;
+  std::vector<double> blob;
+  snap.encode(blob);
+  return emit_blob(blob, out, cap, needed);
+}
+
+uint64_t cofactor_dense_len(int n_num, cofactor_kind kind) {
+  return 1 + (uint64_t)n_num + (kind == COFACTOR_NB ? (uint64_t)n_num : tri(n_num));
+}
+
+cofactor_status cofactor_agg_export_dense_device(cofactor_agg *a, double *d_out) {
+  if (!a || !d_out) return fail(COFACTOR_ERR_INVALID, "null argument");
+  HostTriple snap;
+  cofactor_status s = snapshot(a, snap, /*dense_only=*/true);
+  if (s != COFACTOR_OK) return s;
+  std::vector<double> v;
+  v.push_back(snap.N);
+  v.insert(v.end(), snap.lin.begin(), snap.lin.end());
+  v.insert(v.end(), snap.quad.begin(), snap.quad.end());
+  DeviceGuard guard(a->ctx->device);
+  HIP_TRY(hipMemcpyAsync(d_out, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, a->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_import_dense_device(cofactor_agg *a, const double *d_in) {
+  if (!a || !d_in) return fail(COFACTOR_ERR_INVALID, "null argument");
+  // 1. pull everything the device holds into the host accumulator ...
+  HostTriple snap;
+  cofactor_status s = snapshot(a, snap);
+  if (s != COFACTOR_OK) return s;
+  DeviceGuard guard(a->ctx->device);
+  hipStream_t st = a->ctx->stream;
+  std::vector<double> v(cofactor_dense_len(a->n, (cofactor_kind)a->kind));
+  HIP_TRY(hipMemcpyAsync(v.data(), d_in, v.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemsetAsync(a->d_acc, 0, sizeof(double) * GRAM_ACC_LEN, st));
+  if (a->cat_ready) {
+    HIP_TRY(hipMemsetAsync(a->D.cnt, 0, sizeof(unsigned long long) * std::max(1, a->L.n_cnt), st));
+    HIP_TRY(hipMemsetAsync(a->D.s, 0, sizeof(double) * std::max(1, a->L.n_s), st));
+    HIP_TRY(hipMemsetAsync(a->D.p, 0, sizeof(unsigned long long) * std::max(1, a->L.n_p), st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  a->dev_rows = 0;
+  a->host = std::move(snap);
+  // 2. ... then replace its dense totals by the reduced ones
+  a->host.N = v[0];
+  for (int k = 0; k < a->n; k++) a->host.lin[k] = v[1 + k];
+  for (size_t k = 0; k < a->host.quad.size(); k++) a->host.quad[k] = v[1 + a->n + k];
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_lift_host(const float *const *num, int n_num, const int32_t *const *cat,
+                                   int n_cat, uint64_t rows, cofactor_kind kind, double *out,
+                                   uint64_t cap, uint64_t *needed, uint64_t *offsets) {
+  if (n_num < 0 || n_cat < 0 || (n_num > 0 && !num) || (n_cat > 0 && !cat))
+    return fail(COFACTOR_ERR_INVALID, "bad column arguments");
+  std::vector<double> blob;
+  ListTriple t;
+  for (uint64_t r = 0; r < rows; r++) {
+    if (offsets) offsets[r] = blob.size();
+    lift_row(num, n_num, cat, n_cat, r, (int)kind, t);
+    blob_encode(t, blob);
+  }
+  if (offsets) offsets[rows] = blob.size();
+  return emit_blob(blob, out, cap, needed);
+}
+
+cofactor_status cofactor_triple_multiply(const double *a, const double *b, double *out, uint64_t cap,
+                                         uint64_t *needed) {
+  if (!a || !b) return fail(COFACTOR_ERR_INVALID, "null argument");
+  ListTriple A, B, R;
+  std::string err;
+  if (!blob_decode(a, A, err) || !blob_decode(b, B, err)) return fail(COFACTOR_ERR_INVALID, err);
+  if (!multiply(A, B, R, err)) return fail(COFACTOR_ERR_INVALID, err);
+  std::vector<double> blob;
+  blob_encode(R, blob);
+  return emit_blob(blob, out, cap, needed);
+}
+
+static cofactor_status add_sub_impl(const double *a, const double *b, bool sub, double *out,
+                                    uint64_t cap, uint64_t *needed) {
+  if (!a || !b) return fail(COFACTOR_ERR_INVALID, "null argument");
+  ListTriple A, B, R;
+  std::string err, warn;
+  if (!blob_decode(a, A, err) || !blob_decode(b, B, err)) return fail(COFACTOR_ERR_INVALID, err);
+  if (A.kind != B.kind) return fail(COFACTOR_ERR_INVALID, "triple kinds differ");
+  add_sub(A, B, sub, R, warn);
+  g_err = warn;                                   // "" unless a subtract met an unknown key
+  std::vector<double> blob;
+  blob_encode(R, blob);
+  return emit_blob(blob, out, cap, needed);
+}
+
+cofactor_status cofactor_triple_add(const double *a, const double *b, double *out, uint64_t cap,
+                                    uint64_t *needed) {
+  return add_sub_impl(a, b, false, out, cap, needed);
+}
+cofactor_status cofactor_triple_sub(const double *a, const double *b, double *out, uint64_t cap,
+                                    uint64_t *needed) {
+  return add_sub_impl(a, b, true, out, cap, needed);
+}
+
+uint64_t cofactor_blob_len(const double *blob) { return blob_len(blob); }
+
+}  // extern "C"

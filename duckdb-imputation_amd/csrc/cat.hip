@@ -1,0 +1,282 @@
+// Categorical part of sum_to_triple_n_m / sum_to_nb_agg_n_m on gfx950: per categorical column
+// the per-key row count and per-key sums of every numeric column (lin_cat, quad_num_cat), and per
+// column pair the per-(key1,key2) row count (quad_cat).
+//
+// Replaces the reference's std::map find/insert per row per column and per column pair
+// (duckdb_extension/src/triple/sum/sum_no_lift.cpp:157-214, sum_to_nb_agg.cpp:124-145).
+//
+// Keys are arbitrary int32.  Each column has a device dictionary (open addressing, 64-bit slots
+// "valid<<32 | key") that maps a key to a dense code in insertion order; counts, sums and pair
+// counts live in dense code-indexed tables.  The sorted key order the reference's std::map gives
+// its output is produced at finalize on the host (tables are tiny compared with the scan).
+//
+// One update is: cat_insert (find unseen keys) -> cat_assign_codes -> [host: grow tables if a
+// column outgrew them] -> cat_accumulate.  cat_accumulate keeps private copies of the tables in
+// LDS when they fit (ds_add_u32 / ds_add_f64) and flushes them with global atomics at the end;
+// otherwise it adds straight into the global tables.
+#include "device.hpp"
+
+namespace cofactor {
+
+namespace {
+
+constexpr int CAT_THREADS = 1024;
+
+__device__ __forceinline__ unsigned hash_key(int32_t key, int cap) {
+  // cap is a power of two >= 2
+  return ((unsigned)key * 0x9E3779B1u) >> (32 - (31 - __builtin_clz(cap)));
+}
+__device__ __forceinline__ unsigned long long pack_key(int32_t key) {
+  return (1ull << 32) | (unsigned long long)(unsigned)key;
+}
+
+__global__ __launch_bounds__(256) void cat_insert_kernel(CatCols cols, uint64_t rows, CatLayout L,
+                                                         CatDevice D) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+    for (int c = 0; c < L.m; c++) {
+      const int32_t key = cols.p[c][r];
+      const unsigned long long want = pack_key(key);
+      const int cap = L.ht_cap[c];
+      unsigned long long *slots = D.ht_slot + L.ht_off[c];
+      unsigned h = hash_key(key, cap);
+      int probe = 0;
+      for (; probe < cap; probe++) {
+        unsigned long long cur = slots[h];
+        if (cur == want) break;
+        if (cur == 0ull) {
+          const unsigned long long old = atomicCAS(&slots[h], 0ull, want);
+          if (old == 0ull || old == want) break;
+        }
+        h = (h + 1) & (cap - 1);
+      }
+      if (probe == cap) D.flags[0] = 1;           // dictionary full: host grows it and re-runs
+    }
+  }
+}
+
+// Every occupied slot without a code draws the column's next code.
+__global__ __launch_bounds__(256) void cat_assign_kernel(CatLayout L, CatDevice D) {
+  const int c = blockIdx.y;
+  if (c >= L.m) return;
+  const int cap = L.ht_cap[c];
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += gridDim.x * blockDim.x) {
+    const int g = L.ht_off[c] + s;
+    if (D.ht_slot[g] != 0ull && D.ht_code[g] < 0) D.ht_code[g] = atomicAdd(&D.nkeys[c], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void cat_rehash_kernel(CatLayout Lo, CatDevice Do, CatLayout Ln,
+                                                         CatDevice Dn) {
+  const int c = blockIdx.y;
+  if (c >= Lo.m) return;
+  const int cap_o = Lo.ht_cap[c], cap_n = Ln.ht_cap[c];
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < cap_o; s += gridDim.x * blockDim.x) {
+    const unsigned long long v = Do.ht_slot[Lo.ht_off[c] + s];
+    if (v == 0ull) continue;
+    const int32_t key = (int32_t)(unsigned)(v & 0xffffffffull);
+    unsigned h = hash_key(key, cap_n);
+    for (int probe = 0; probe < cap_n; probe++) {
+      const unsigned long long old = atomicCAS(&Dn.ht_slot[Ln.ht_off[c] + h], 0ull, v);
+      if (old == 0ull) { Dn.ht_code[Ln.ht_off[c] + h] = Do.ht_code[Lo.ht_off[c] + s]; break; }
+      h = (h + 1) & (cap_n - 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cat_relayout_kernel(CatLayout Lo, CatDevice Do, CatLayout Ln,
+                                                           CatDevice Dn) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (int i = tid; i < Lo.n_cnt; i += nth) {     // counts: same code, new column offset
+    int c = 0;
+    while (c + 1 < Lo.m && i >= Lo.cnt_off[c + 1]) c++;
+    Dn.cnt[Ln.cnt_off[c] + (i - Lo.cnt_off[c])] = Do.cnt[i];
+  }
+  if (Lo.kind == 0) {
+    for (int i = tid; i < Lo.n_s; i += nth) {     // sums: [code][k] keeps its shape
+      int c = 0;
+      while (c + 1 < Lo.m && i >= Lo.s_off[c + 1]) c++;
+      Dn.s[Ln.s_off[c] + (i - Lo.s_off[c])] = Do.s[i];
+    }
+    const int npairs = Lo.m * (Lo.m + 1) / 2;
+    for (int i = tid; i < Lo.n_p; i += nth) {     // pairs: row stride kc[c2] changes
+      int q = 0;
+      while (q + 1 < npairs && i >= Lo.p_off[q + 1]) q++;
+      int c1 = 0, rem = q;
+      while (rem >= Lo.m - c1) { rem -= Lo.m - c1; c1++; }
+      const int c2 = c1 + rem;
+      const int local = i - Lo.p_off[q];
+      const int code1 = local / Lo.kc[c2], code2 = local % Lo.kc[c2];
+      Dn.p[Ln.p_off[q] + code1 * Ln.kc[c2] + code2] = Do.p[i];
+    }
+  }
+}
+
+// Looks `key` up in a dictionary that is known to contain it.
+template <typename SlotPtr, typename CodePtr>
+__device__ __forceinline__ int lookup_code(SlotPtr slots, CodePtr codes, int cap, int32_t key) {
+  const unsigned long long want = pack_key(key);
+  unsigned h = hash_key(key, cap);
+  for (int probe = 0; probe < cap; probe++) {
+    if (slots[h] == want) return codes[h];
+    h = (h + 1) & (cap - 1);
+  }
+  return -1;
+}
+
+template <bool LDS_TABLES, int KIND>
+__global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num, CatCols cat,
+                                                                     uint64_t rows, CatLayout L,
+                                                                     CatDevice D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  // LDS carve (LDS_TABLES only): slots (8 B) | sums (8 B) | codes | counts | pairs (4 B each)
+  unsigned long long *l_slot = reinterpret_cast<unsigned long long *>(lds_raw);
+  double *l_s = reinterpret_cast<double *>(l_slot + L.n_slots);
+  int32_t *l_code = reinterpret_cast<int32_t *>(l_s + (KIND == 0 ? L.n_s : 0));
+  unsigned *l_cnt = reinterpret_cast<unsigned *>(l_code + L.n_slots);
+  unsigned *l_p = l_cnt + L.n_cnt;
+
+  const int tid = threadIdx.x;
+  if (LDS_TABLES) {
+    for (int i = tid; i < L.n_slots; i += CAT_THREADS) { l_slot[i] = D.ht_slot[i]; l_code[i] = D.ht_code[i]; }
+    for (int i = tid; i < L.n_cnt; i += CAT_THREADS) l_cnt[i] = 0u;
+    if (KIND == 0) {
+      for (int i = tid; i < L.n_s; i += CAT_THREADS) l_s[i] = 0.0;
+      for (int i = tid; i < L.n_p; i += CAT_THREADS) l_p[i] = 0u;
+    }
+    __syncthreads();
+  }
+
+  const uint64_t stride = (uint64_t)gridDim.x * CAT_THREADS;
+  for (uint64_t r = (uint64_t)blockIdx.x * CAT_THREADS + tid; r < rows; r += stride) {
+    int code[COFACTOR_MAX_CAT];
+#pragma unroll
+    for (int c = 0; c < COFACTOR_MAX_CAT; c++) {
+      if (c < L.m) {
+        const int32_t key = cat.p[c][r];
+        if (LDS_TABLES) code[c] = lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], key);
+        else code[c] = lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], key);
+      }
+    }
+    bool known = true;
+#pragma unroll
+    for (int c = 0; c < COFACTOR_MAX_CAT; c++)
+      if (c < L.m) known = known && code[c] >= 0 && code[c] < L.kc[c];
+    if (!known) { D.flags[1] = 1; continue; }     // never index a table with a bad code
+#pragma unroll
+    for (int c = 0; c < COFACTOR_MAX_CAT; c++) {
+      if (c < L.m) {
+        if (LDS_TABLES) atomicAdd(&l_cnt[L.cnt_off[c] + code[c]], 1u);
+        else atomicAdd(&D.cnt[L.cnt_off[c] + code[c]], 1ull);
+      }
+    }
+    if (KIND == 0) {
+      for (int k = 0; k < L.n; k++) {
+        const double x = (double)num.p[k][r];
+#pragma unroll
+        for (int c = 0; c < COFACTOR_MAX_CAT; c++) {
+          if (c < L.m) {
+            const int idx = L.s_off[c] + code[c] * L.n + k;
+            if (LDS_TABLES) unsafeAtomicAdd(&l_s[idx], x);
+            else unsafeAtomicAdd(&D.s[idx], x);
+          }
+        }
+      }
+      int q = 0;
+#pragma unroll
+      for (int c1 = 0; c1 < COFACTOR_MAX_CAT; c1++) {
+#pragma unroll
+        for (int c2 = c1; c2 < COFACTOR_MAX_CAT; c2++) {
+          if (c2 < L.m) {
+            const int idx = L.p_off[q] + code[c1] * L.kc[c2] + code[c2];
+            if (LDS_TABLES) atomicAdd(&l_p[idx], 1u);
+            else atomicAdd(&D.p[idx], 1ull);
+            q++;
+          }
+        }
+      }
+    }
+  }
+
+  if (LDS_TABLES) {
+    __syncthreads();
+    for (int i = tid; i < L.n_cnt; i += CAT_THREADS)
+      if (l_cnt[i]) atomicAdd(&D.cnt[i], (unsigned long long)l_cnt[i]);
+    if (KIND == 0) {
+      for (int i = tid; i < L.n_s; i += CAT_THREADS)
+        if (l_s[i] != 0.0) unsafeAtomicAdd(&D.s[i], l_s[i]);
+      for (int i = tid; i < L.n_p; i += CAT_THREADS)
+        if (l_p[i]) atomicAdd(&D.p[i], (unsigned long long)l_p[i]);
+    }
+  }
+}
+
+}  // namespace
+
+size_t cat_lds_bytes(const CatLayout &L) {
+  size_t b = (size_t)L.n_slots * (8 + 4) + (size_t)L.n_cnt * 4;
+  if (L.kind == 0) b += (size_t)L.n_s * 8 + (size_t)L.n_p * 4;
+  return b;
+}
+
+hipError_t launch_cat_insert(const CatCols &cols, uint64_t rows, const CatLayout &L,
+                             const CatDevice &D, hipStream_t stream) {
+  if (rows == 0 || L.m == 0) return hipSuccess;
+  uint64_t blocks = (rows + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cat_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, cols, rows, L, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_assign_codes(const CatLayout &L, const CatDevice &D, hipStream_t stream) {
+  if (L.m == 0) return hipSuccess;
+  int maxcap = 0;
+  for (int c = 0; c < L.m; c++) maxcap = L.ht_cap[c] > maxcap ? L.ht_cap[c] : maxcap;
+  int bx = (maxcap + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(cat_assign_kernel, dim3(bx, L.m), dim3(256), 0, stream, L, D);
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
+                             const CatDevice &Dnew, hipStream_t stream) {
+  if (Lold.m == 0) return hipSuccess;
+  int maxcap = 0;
+  for (int c = 0; c < Lold.m; c++) maxcap = Lold.ht_cap[c] > maxcap ? Lold.ht_cap[c] : maxcap;
+  int bx = (maxcap + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(cat_rehash_kernel, dim3(bx, Lold.m), dim3(256), 0, stream, Lold, Dold, Lnew, Dnew);
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
+                               const CatDevice &Dnew, hipStream_t stream) {
+  if (Lold.m == 0) return hipSuccess;
+  hipLaunchKernelGGL(cat_relayout_kernel, dim3(512), dim3(256), 0, stream, Lold, Dold, Lnew, Dnew);
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
+                                 const CatLayout &L, const CatDevice &D, bool lds_tables, int grid,
+                                 hipStream_t stream) {
+  if (rows == 0 || L.m == 0) return hipSuccess;
+  const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
+  if ((uint64_t)grid > need) grid = (int)need;
+  const size_t lds = lds_tables ? cat_lds_bytes(L) : 0;
+#define GO(LT, K)                                                                                 \
+  do {                                                                                            \
+    if (lds > 48 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void *)cat_accumulate_kernel<LT, K>,              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+      if (e != hipSuccess) return e;                                                              \
+    }                                                                                             \
+    hipLaunchKernelGGL((cat_accumulate_kernel<LT, K>), dim3(grid), dim3(CAT_THREADS), lds,        \
+                       stream, num, cat, rows, L, D);                                             \
+  } while (0)
+  if (lds_tables) { if (L.kind == 0) GO(true, 0); else GO(true, 1); }
+  else { if (L.kind == 0) GO(false, 0); else GO(false, 1); }
+#undef GO
+  return hipGetLastError();
+}
+
+}  // namespace cofactor

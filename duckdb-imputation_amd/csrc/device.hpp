@@ -1,0 +1,85 @@
+// Internal device-side declarations shared by the HIP translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/cofactor_hip.h"
+
+namespace cofactor {
+
+// ---- dense Gram kernel geometry ---------------------------------------------------------------
+// One v_mfma_f32_4x4x1_16b_f32 multiplies 16 independent 4x1 by 1x4 blocks.  The n <= 20 numeric
+// columns are cut into NB = ceil(n/4) <= 5 column blocks, so the upper triangle of the n x n Gram
+// matrix is NB(NB+1)/2 <= 15 block pairs: ONE MFMA per input row.  Lane l = 4*b + t serves block
+// pair b = (bi, bj): it feeds x[4*bi + t] as A and x[4*bj + t] as B and receives, in accumulator
+// register i, the sum over rows of x[4*bi + i] * x[4*bj + t].
+constexpr int GRAM_TILE_ROWS = 256;               // rows per LDS tile
+constexpr int GRAM_COL_STRIDE = GRAM_TILE_ROWS + 4;  // floats; +4 keeps 16-B alignment and walks
+                                                     // the 64 ds_read_b128 banks 4 per column
+constexpr int GRAM_THREADS = 256;
+constexpr int GRAM_SLOTS = 5;                     // per lane: 4 accumulator rows + 1 column sum
+constexpr int GRAM_ACC_LEN = 64 * GRAM_SLOTS;     // doubles in one dense accumulator image
+
+struct NumCols { const float *p[COFACTOR_MAX_NUM]; };
+struct CatCols { const int32_t *p[COFACTOR_MAX_CAT]; };
+
+__host__ __device__ inline int gram_pair_index(int bi, int bj, int nb) {  // bi <= bj
+  return bi * nb - bi * (bi - 1) / 2 + (bj - bi);
+}
+// where Q[j][k] (j <= k) and lin[c] live in an accumulator image ([slot][lane])
+__host__ __device__ inline int gram_quad_pos(int j, int k, int n) {
+  const int nb = (n + 3) / 4;
+  return (j & 3) * 64 + 4 * gram_pair_index(j >> 2, k >> 2, nb) + (k & 3);
+}
+__host__ __device__ inline int gram_lin_pos(int c, int n) {
+  const int nb = (n + 3) / 4;
+  return 4 * 64 + 4 * gram_pair_index(c >> 2, c >> 2, nb) + (c & 3);
+}
+
+// Launches the Gram pass over `rows` rows of n columns and adds the result into acc[GRAM_ACC_LEN]
+// (device doubles).  partials must hold grid * GRAM_ACC_LEN doubles.
+hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
+                       double *acc, hipStream_t stream);
+
+// ---- categorical tables -----------------------------------------------------------------------
+constexpr int MAX_PAIRS = COFACTOR_MAX_CAT * (COFACTOR_MAX_CAT + 1) / 2;
+
+// Everything a kernel needs to know about where a column's dictionary and tables live.
+struct CatLayout {
+  int n, m, kind;
+  int ht_cap[COFACTOR_MAX_CAT];   // dictionary slots per column (power of two)
+  int ht_off[COFACTOR_MAX_CAT];   // first slot of the column in ht_slot / ht_code
+  int kc[COFACTOR_MAX_CAT];       // code capacity of the column (>= its number of keys)
+  int cnt_off[COFACTOR_MAX_CAT];  // counts:  cnt[cnt_off[c] + code]
+  int s_off[COFACTOR_MAX_CAT];    // sums:    s[s_off[c] + code * n + k]
+  int p_off[MAX_PAIRS];           // pairs:   p[p_off[q] + code1 * kc[c2] + code2]
+  int n_slots, n_cnt, n_s, n_p;
+};
+
+struct CatDevice {
+  unsigned long long *ht_slot;    // (1 << 32 | (uint32)key), 0 = empty
+  int32_t *ht_code;               // code of the key in that slot, -1 = not assigned yet
+  int32_t *nkeys;                 // per column number of keys (device counters)
+  int32_t *flags;                 // [0] = a dictionary ran full during insert
+  unsigned long long *cnt;
+  double *s;
+  unsigned long long *p;
+};
+
+size_t cat_lds_bytes(const CatLayout &L);
+
+hipError_t launch_cat_insert(const CatCols &cols, uint64_t rows, const CatLayout &L,
+                             const CatDevice &D, hipStream_t stream);
+hipError_t launch_cat_assign_codes(const CatLayout &L, const CatDevice &D, hipStream_t stream);
+hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
+                                 const CatLayout &L, const CatDevice &D, bool lds_tables, int grid,
+                                 hipStream_t stream);
+// re-inserts every (key, code) of the old dictionary into the new one (dictionary growth)
+hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
+                             const CatDevice &Dnew, hipStream_t stream);
+// copies the count / sum / pair tables from the old strides to the new ones (code growth)
+hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
+                               const CatDevice &Dnew, hipStream_t stream);
+
+}  // namespace cofactor

@@ -1,0 +1,210 @@
+// Dense part of sum_to_triple_n_m on gfx950: lin_agg (column sums) and quad_agg (upper triangle of
+// X^T X) of n <= 20 float columns, streamed once from HBM.
+//
+// Replaces the reference's n(n+1)/2 passes over each DataChunk
+// (duckdb_extension/src/triple/sum/sum_no_lift.cpp:119-146).
+//
+// Shape of the kernel (DESIGN.md "gram_kernel"):
+//   * a 256-thread workgroup walks 256-row tiles of the table, grid-stride;
+//   * each tile's n columns are fetched with coalesced 16-B/lane global loads (one wave-instruction
+//     = 1 KiB of ONE column) one tile ahead of use, and parked in LDS column-major
+//     [column][row] with a +4-float column stride;
+//   * each wave owns 64 rows of the tile; per 4 rows every lane reads its A and B operand columns
+//     with two ds_read_b128 and issues 4 v_mfma_f32_4x4x1_16b_f32 — one MFMA per row covers all
+//     <= 15 4x4 blocks of the upper triangle (device.hpp);
+//   * fp32 MFMA chains are cut every FLUSH_TILES tiles and folded into fp64 registers (the
+//     reference's fp32 running sums saturate at 2^24);
+//   * per-workgroup fp64 images go to a [slot][workgroup] scratch array and a second small kernel
+//     adds them, in a fixed order, into the aggregate's accumulator image.
+#include "device.hpp"
+
+namespace cofactor {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int FLUSH_TILES = 4;  // 4 tiles x 16 rows per chain = 64 fp32 adds between fp64 folds
+
+template <bool ALIGNED>
+__device__ __forceinline__ float4 load_rows4_full(const float *__restrict__ col, uint64_t row) {
+  if (ALIGNED) return *reinterpret_cast<const float4 *>(col + row);
+  return make_float4(col[row], col[row + 1], col[row + 2], col[row + 3]);
+}
+
+// last, partial tile only: rows past the end contribute zeros (neutral for every sum)
+__device__ __forceinline__ float4 load_rows4_tail(const float *__restrict__ col, uint64_t row,
+                                                  uint64_t rows) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < rows) v.x = col[row];
+  if (row + 1 < rows) v.y = col[row + 1];
+  if (row + 2 < rows) v.z = col[row + 2];
+  if (row + 3 < rows) v.w = col[row + 3];
+  return v;
+}
+
+template <int N, bool ALIGNED>
+__global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64_t rows,
+                                                            double *__restrict__ partials) {
+  constexpr int NB = (N + 3) / 4;
+  constexpr int NPAIR = NB * (NB + 1) / 2;
+  constexpr int NBC = 4 * NB;                     // data columns incl. zero padding to 4*NB
+  constexpr int CS = GRAM_COL_STRIDE;
+  constexpr int LD = (N * 64 + GRAM_THREADS - 1) / GRAM_THREADS;  // float4 loads / thread / tile
+  // columns [0,N) data, [N,NBC) zero padding, column NBC all-zero (operand of unused blocks)
+  constexpr int TILE_FLOATS = (NBC + 1) * CS > 8 * GRAM_ACC_LEN ? (NBC + 1) * CS : 8 * GRAM_ACC_LEN;
+  __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS];  // also the wave-fold scratch
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int colA = NBC, colB = NBC;
+  {
+    const int b = lane >> 2, t = lane & 3;
+    if (b < NPAIR) {
+      int bi = 0, rem = b;
+      while (rem >= NB - bi) { rem -= NB - bi; bi++; }
+      colA = 4 * bi + t;
+      colB = 4 * (bi + rem) + t;
+    }
+  }
+  for (int i = tid; i < (NBC + 1 - N) * CS; i += GRAM_THREADS) tile[N * CS + i] = 0.f;
+
+  const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
+  float4 pre[LD];
+  auto fetch = [&](uint64_t t) {
+    const uint64_t r0 = t * GRAM_TILE_ROWS;
+    if (r0 + GRAM_TILE_ROWS <= rows) {            // whole tile in range: straight-line loads
+#pragma unroll
+      for (int i = 0; i < LD; i++) {
+        const int col = wave + 4 * i;             // wave-uniform: q = tid + 256 i, col = q / 64
+        if (4 * i + 3 < N || col < N) pre[i] = load_rows4_full<ALIGNED>(cols.p[col], r0 + 4 * lane);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < LD; i++) {
+        const int col = wave + 4 * i;
+        if (4 * i + 3 < N || col < N) pre[i] = load_rows4_tail(cols.p[col], r0 + 4 * lane, rows);
+      }
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < LD; i++) {
+      const int col = wave + 4 * i;
+      if (4 * i + 3 < N || col < N) *reinterpret_cast<float4 *>(&tile[col * CS + 4 * lane]) = pre[i];
+    }
+  };
+
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  float ls = 0.f;
+  double dq0 = 0, dq1 = 0, dq2 = 0, dq3 = 0, dl = 0;
+  const float *pa = tile + colA * CS + wave * 64;
+  const float *pb = tile + colB * CS + wave * 64;
+
+  uint64_t t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  int since_flush = 0;
+  while (t < ntiles) {
+    park();
+    __syncthreads();
+    const uint64_t tn = t + gridDim.x;
+    if (tn < ntiles) fetch(tn);                   // next tile's loads fly under this tile's MFMAs
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+      const float4 a = *reinterpret_cast<const float4 *>(pa + 4 * it);
+      const float4 b = *reinterpret_cast<const float4 *>(pb + 4 * it);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b.z, acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b.w, acc3, 0, 0, 0);
+      ls += (a.x + a.y) + (a.z + a.w);
+    }
+    if (++since_flush == FLUSH_TILES) {
+      dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
+      dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
+      dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
+      dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
+      dl += (double)ls;
+      acc0 = acc1 = acc2 = acc3 = f32x4{0, 0, 0, 0};
+      ls = 0.f;
+      since_flush = 0;
+    }
+    __syncthreads();                              // everyone done reading before the next park()
+    t = tn;
+  }
+  dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
+  dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
+  dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
+  dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
+  dl += (double)ls;
+
+  // fold the 4 waves (fixed order) through LDS, then one image per workgroup
+  double *red = reinterpret_cast<double *>(tile);  // 4 waves x 320 doubles = 10 KiB
+  static_assert(sizeof(double) * 4 * GRAM_ACC_LEN <= sizeof(float) * TILE_FLOATS,
+                "wave fold scratch must fit the tile");
+  __syncthreads();
+  double *mine = red + wave * GRAM_ACC_LEN;
+  mine[0 * 64 + lane] = dq0;
+  mine[1 * 64 + lane] = dq1;
+  mine[2 * 64 + lane] = dq2;
+  mine[3 * 64 + lane] = dq3;
+  mine[4 * 64 + lane] = dl;
+  __syncthreads();
+  for (int i = tid; i < GRAM_ACC_LEN; i += GRAM_THREADS) {
+    const double v = ((red[i] + red[GRAM_ACC_LEN + i]) + red[2 * GRAM_ACC_LEN + i]) +
+                     red[3 * GRAM_ACC_LEN + i];
+    partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+// acc[i] += sum over workgroups of partials[i][wg], fixed tree order: bitwise reproducible.
+__global__ __launch_bounds__(256) void gram_fold_kernel(const double *__restrict__ partials,
+                                                        int nwg, double *__restrict__ acc) {
+  __shared__ double red[256];
+  const int i = blockIdx.x;
+  double v = 0;
+  for (int w = threadIdx.x; w < nwg; w += 256) v += partials[(uint64_t)i * nwg + w];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[i] += red[0];
+}
+
+template <int N>
+hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partials,
+                    hipStream_t stream) {
+  bool aligned = true;
+  for (int k = 0; k < N; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(cols.p[k]) & 15) == 0);
+  if (aligned)
+    hipLaunchKernelGGL((gram_kernel<N, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials);
+  else
+    hipLaunchKernelGGL((gram_kernel<N, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
+                       double *acc, hipStream_t stream) {
+  if (rows == 0 || n == 0) return hipSuccess;
+  const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
+  if ((uint64_t)grid > ntiles) grid = (int)ntiles;
+  hipError_t e = hipErrorInvalidValue;
+  switch (n) {
+#define CASE(N) case N: e = launch_n<N>(cols, rows, grid, partials, stream); break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+    CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
+#undef CASE
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gram_fold_kernel, dim3(GRAM_ACC_LEN), dim3(256), 0, stream, partials, grid, acc);
+  return hipGetLastError();
+}
+
+}  // namespace cofactor

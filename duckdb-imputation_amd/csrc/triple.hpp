@@ -1,0 +1,58 @@
+// Host-side triple containers of libcofactor_hip: the flat blob codec, the sparse accumulator a
+// cofactor_agg keeps for everything that is not (yet) in device tables, and the scalar ring ops.
+// No HIP in here.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace cofactor {
+
+inline uint64_t tri(uint64_t k) { return k * (k + 1) / 2; }
+
+// Mirror of one blob: lists exactly as they sit in the blob (see include/cofactor_hip.h).
+struct KeyVal { int32_t key; double val; };
+struct PairVal { int32_t k1, k2; double val; };
+struct ListTriple {
+  int kind = 0, n = 0, m = 0;
+  double N = 0;
+  std::vector<double> lin, quad;
+  std::vector<std::vector<KeyVal>> lin_cat;   // m
+  std::vector<std::vector<KeyVal>> num_cat;   // n*m (kind 0)
+  std::vector<std::vector<PairVal>> cat_cat;  // tri(m) (kind 0)
+};
+
+// Walks one blob; returns its length in doubles (0 on a malformed header).
+uint64_t blob_len(const double *b);
+bool blob_decode(const double *b, ListTriple &t, std::string &err);
+void blob_encode(const ListTriple &t, std::vector<double> &out);
+
+// Sparse accumulator (wide: double sums, exact integer counts up to 2^53).
+struct HostTriple {
+  int kind = 0, n = 0, m = 0;
+  double N = 0;
+  std::vector<double> lin, quad;
+  // per categorical column: key -> [count, S_0 .. S_{n-1}]   (kind NB: [count])
+  std::vector<std::map<int32_t, std::vector<double>>> col;
+  // per column pair (c1 <= c2): (key1, key2) -> count        (kind 0 only)
+  std::vector<std::map<std::pair<int32_t, int32_t>, double>> pair;
+
+  void shape(int kind_, int n_, int m_);
+  void clear();
+  // this += one finalised triple (the body of Triple::Sum / sum_nb_agg for one input row)
+  bool add_list(const ListTriple &t, std::string &err);
+  // this += other (SumStateCombine)
+  bool add(const HostTriple &o, std::string &err);
+  void encode(std::vector<double> &out) const;  // SumStateFinalize order
+};
+
+// Scalar ring ops on decoded blobs.
+void lift_row(const float *const *num, int n, const int32_t *const *cat, int m, uint64_t row,
+              int kind, ListTriple &t);
+bool multiply(const ListTriple &A, const ListTriple &B, ListTriple &R, std::string &err);
+bool add_sub(const ListTriple &A, const ListTriple &B, bool subtract, ListTriple &R,
+             std::string &warn);
+
+}  // namespace cofactor

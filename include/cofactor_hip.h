@@ -1,0 +1,163 @@
+/*
+ * cofactor_hip.h — C ABI of libcofactor_hip.so: the MI355X (gfx950) implementation of the
+ * cofactor-triple ("ring") aggregate hot path of eddbase/duckdb-imputation.
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference
+ * interface it stands in for (paths relative to the reference repo root).  Plain pointers and
+ * sizes only; no C++ / torch / DuckDB types.  No exceptions cross it: every call returns a
+ * cofactor_status and cofactor_last_error() gives the thread-local message.
+ *
+ * Threading contract (mirrors DuckDB's: duckdb_extension/src/triple/sum/sum_state.cpp has no
+ * locks): distinct cofactor_agg handles may be used from different threads concurrently; one
+ * handle is used by one thread at a time.
+ *
+ * ---------------------------------------------------------------------------------------------
+ * Flat triple blob — the host representation of ONE finalised triple: an array of doubles (all
+ * int32 keys / counts / float sums are exactly representable), in the order in which the
+ * reference's finalize fills its nested vectors (sum_state.cpp:116-464):
+ *
+ *   [0] kind (0 = COFACTOR_TRIPLE, 1 = COFACTOR_NB)     [1] n (#numeric)     [2] m (#categorical)
+ *   [3] N
+ *   lin[n]
+ *   quad[n(n+1)/2]  row-major upper triangle (kind 0)    |    quad[n] diagonal (kind 1)
+ *   lin_cat:       m lists, each:  len, len x (key, count)              keys ascending
+ *   quad_num_cat:  n*m lists, index k*m + c, each: len, len x (key, sum of x_k)   (kind 0 only)
+ *   quad_cat:      m(m+1)/2 lists (c1 outer, c2 >= c1), each: len, len x (key1, key2, count),
+ *                  lexicographically ascending                                     (kind 0 only)
+ *
+ * Sums are carried in double; a DuckDB FLOAT field is the value rounded to float.
+ * ---------------------------------------------------------------------------------------------
+ */
+#ifndef COFACTOR_HIP_H
+#define COFACTOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COFACTOR_ABI_VERSION 1
+/* sum_to_triple_<x>_<y> is registered for x,y in 0..20 (the reference registers 0..19,
+ * duckdb_imputation_extension.cpp:80-84; README.md:136 documents "up to 20"). */
+#define COFACTOR_MAX_NUM 20
+#define COFACTOR_MAX_CAT 20
+
+typedef enum {
+  COFACTOR_OK = 0,
+  COFACTOR_ERR_INVALID = 1,     /* bad argument (null pointer, n/m out of range, kind mismatch)  */
+  COFACTOR_ERR_NO_DEVICE = 2,   /* no usable gfx950 device / HIP runtime error at context create */
+  COFACTOR_ERR_HIP = 3,         /* a HIP call failed; message carries hipGetErrorString           */
+  COFACTOR_ERR_CAPACITY = 4,    /* output buffer too small; *needed tells how many doubles        */
+  COFACTOR_ERR_UNSUPPORTED = 5  /* shape outside what the device path handles (message says which)*/
+} cofactor_status;
+
+typedef enum { COFACTOR_TRIPLE = 0, COFACTOR_NB = 1 } cofactor_kind;
+
+typedef struct cofactor_ctx cofactor_ctx; /* one GPU: device id, stream, workspaces            */
+typedef struct cofactor_agg cofactor_agg; /* one aggregate state (what a Triple::SumState is)   */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *cofactor_last_error(void);
+int cofactor_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Opens HIP device `device`.  Fails with COFACTOR_ERR_NO_DEVICE when there is no GPU: there is
+ * no CPU fallback in this library. */
+cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out);
+void cofactor_ctx_destroy(cofactor_ctx *ctx);
+cofactor_status cofactor_ctx_synchronize(cofactor_ctx *ctx);
+/* The hipStream_t all of this context's kernels are launched on (for event timing). */
+void *cofactor_ctx_stream(cofactor_ctx *ctx);
+
+/* ---- aggregate state ------------------------------------------------------------------------
+ * Replaces Triple::SumState + StateFunction::Initialize/Destroy
+ * (duckdb_extension/src/include/triple/sum/sum_state.h:14-57).  n/m are what the reference
+ * derives from the argument types on the first update (sum_no_lift.cpp:66-73,96-99). */
+cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cofactor_kind kind,
+                                    cofactor_agg **out);
+void cofactor_agg_destroy(cofactor_agg *agg);
+/* Back to the freshly created state (N = 0, all tables empty, dictionaries kept allocated). */
+cofactor_status cofactor_agg_reset(cofactor_agg *agg);
+
+/* update — Triple::SumNoLift (duckdb_extension/src/triple/sum/sum_no_lift.cpp:53-216) and
+ * Triple::sum_to_nb_agg (duckdb_extension/src/triple/sum/sum_to_nb_agg.cpp:39-146).
+ *
+ * Device form: the columns are resident in this context's HBM (d_num[k] -> float[rows],
+ * d_cat[c] -> int32[rows]; the pointer arrays themselves are host arrays).  Asynchronous on the
+ * context stream.  This is the measured hot path. */
+cofactor_status cofactor_agg_update_device(cofactor_agg *agg, const float *const *d_num,
+                                           const int32_t *const *d_cat, uint64_t rows);
+
+/* Host form: what DuckDB hands the aggregate's update callback — one DataChunk (<= 2048 rows in
+ * DuckDB, any size here) of host columns in UnifiedVectorFormat.  Column k's value for logical
+ * row i is  col[k][ sel && sel[k] ? sel[k][r] : r ]  with  r = row_idx ? row_idx[i] : i
+ * (input_data[k].sel->get_index(i), sum_no_lift.cpp:120; row_idx lists the chunk rows whose
+ * state pointer is this state, sum_no_lift.cpp:84,94,139).  num_sel / cat_sel / row_idx may be
+ * NULL.  Rows are staged in pinned memory and flushed to the GPU in large batches. */
+cofactor_status cofactor_agg_update_host(cofactor_agg *agg, const float *const *num,
+                                         const int32_t *const *cat,
+                                         const uint32_t *const *num_sel,
+                                         const uint32_t *const *cat_sel, const uint32_t *row_idx,
+                                         uint64_t rows);
+
+/* update with already-lifted triples — Triple::Sum (duckdb_extension/src/triple/sum/sum.cpp:
+ * 57-261) and Triple::sum_nb_agg (sum/sum_nb_agg.cpp:45-175): `count` blobs, concatenated,
+ * blob i at blobs[offsets[i] .. offsets[i+1]). */
+cofactor_status cofactor_agg_update_triples(cofactor_agg *agg, const double *blobs,
+                                            const uint64_t *offsets, uint64_t count);
+
+/* combine — Triple::SumStateCombine (duckdb_extension/src/triple/sum/sum_state.cpp:10-114):
+ * dst += src.  src is left unchanged.  Handles may live on different contexts (GPUs). */
+cofactor_status cofactor_agg_combine(cofactor_agg *dst, cofactor_agg *src);
+
+/* finalize — Triple::SumStateFinalize (sum_state.cpp:116-464): writes the flat triple blob.
+ * Two-call protocol: with out == NULL or cap too small returns COFACTOR_ERR_CAPACITY (or OK if
+ * out == NULL) and sets *needed.  Synchronises the context stream. */
+cofactor_status cofactor_agg_finalize(cofactor_agg *agg, double *out, uint64_t cap,
+                                      uint64_t *needed);
+
+/* ---- multi-GPU seam -----------------------------------------------------------
+ * The dense part of the partial triple as ONE device array of doubles
+ *   [ N, lin[n], quad[n(n+1)/2 | n] ]            (cofactor_dense_len(n, kind) values)
+ * so that a single RCCL all-reduce(sum) over the ranks' arrays is the dense half of
+ * SumStateCombine (sum_state.cpp:25,73-83).  export writes the state's current totals into
+ * d_out (device memory, caller-owned, e.g. a torch tensor) on the context stream; import
+ * REPLACES the state's dense totals by the values in d_in (after the all-reduce). */
+uint64_t cofactor_dense_len(int n_num, cofactor_kind kind);
+cofactor_status cofactor_agg_export_dense_device(cofactor_agg *agg, double *d_out);
+cofactor_status cofactor_agg_import_dense_device(cofactor_agg *agg, const double *d_in);
+
+/* ---- scalar ring ops on flat triple blobs (host; tiny per-row work) ---------------------------
+ * All use the two-call protocol of cofactor_agg_finalize. */
+
+/* to_cofactor / to_nb_agg — Triple::CustomLift (duckdb_extension/src/triple/lift.cpp:15-243),
+ * Triple::to_nb_lift (triple/lift_to_nb_agg.cpp:13-136): one blob per row, concatenated;
+ * offsets[rows+1] (may be NULL).  Host columns with the same sel semantics as update_host. */
+cofactor_status cofactor_lift_host(const float *const *num, int n_num, const int32_t *const *cat,
+                                   int n_cat, uint64_t rows, cofactor_kind kind, double *out,
+                                   uint64_t cap, uint64_t *needed, uint64_t *offsets);
+
+/* multiply_triple / multiply_nb_agg — Triple::MultiplyFunction (triple/mul.cpp:19-611),
+ * Triple::multiply_nb (triple/mul_nb.cpp:20-268). */
+cofactor_status cofactor_triple_multiply(const double *a, const double *b, double *out,
+                                         uint64_t cap, uint64_t *needed);
+
+/* Value-level t1 + t2 / t1 - t2 — Triple::sum_triple (imputation/triple/sum.cpp:68-209; also
+ * duckdb_extension/src/triple/sum/sum.cpp:319-460), Triple::sum_nb_triple
+ * (imputation/triple/sum_nb.cpp:38-83), Triple::subtract_triple (imputation/triple/sub.cpp:
+ * 71-217).  On subtract a key missing from `a` is reported via cofactor_last_error() and
+ * skipped, as the reference prints and skips (sub.cpp:28-29). */
+cofactor_status cofactor_triple_add(const double *a, const double *b, double *out, uint64_t cap,
+                                    uint64_t *needed);
+cofactor_status cofactor_triple_sub(const double *a, const double *b, double *out, uint64_t cap,
+                                    uint64_t *needed);
+
+/* Number of doubles in the blob starting at `blob` (walks the lists). */
+uint64_t cofactor_blob_len(const double *blob);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COFACTOR_HIP_H */

@@ -1,0 +1,77 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/cofactor_hip.h
+declares, refuses to run the aggregate without a GPU, and its host-only scalar ring ops
+(lift / multiply / add / sub on flat blobs) reproduce the reference's golden vectors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cofactor_hip
+from oracle import oracle as orc
+from triple_fmt import blob_to_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "cofactor_hip.h")).read()
+    declared = set(re.findall(r"\b(cofactor_[a-z_]+)\s*\(", header))
+    declared -= {"cofactor_status", "cofactor_kind"}
+    assert declared == set(cofactor_hip.SYMBOLS), declared ^ set(cofactor_hip.SYMBOLS)
+    lib = ctypes.CDLL(cofactor_hip.LIB_PATH)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.cofactor_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(cofactor_hip.CofactorError) as e:
+        cofactor_hip.Context(0)
+    assert e.value.status == cofactor_hip.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_blob_len_walks_lists(goldens):
+    want = goldens["test_sum.py"]["tests"][0]["expected"][0]["value"]
+    from triple_fmt import dict_to_blob
+    blob = dict_to_blob(want)
+    assert cofactor_hip.blob_len(blob) == len(blob)
+    assert cofactor_hip.blob_len(np.array([7.0, 1, 1, 1])) == 0          # bad kind
+
+
+def test_host_ring_ops_match_goldens(goldens, ref_table):
+    """to_cofactor / multiply_triple golden literals through the product's host ops."""
+    for fname, kind in (("test_lift.py", cofactor_hip.TRIPLE), ("test_nb_lift.py", cofactor_hip.NB)):
+        T = ref_table[fname]
+        want = sorted(goldens[fname]["tests"][0]["expected"], key=lambda e: e["row"])
+        got = cofactor_hip.lift_host(T.num("abc"), T.cat("def"), kind)
+        assert [blob_to_dict(g, "num") for g in got] == [w["value"] for w in want]
+
+
+def test_add_then_sub_round_trip(goldens):
+    from triple_fmt import dict_to_blob
+    exp = sorted(goldens["test_sum.py"]["tests"][1]["expected"], key=lambda e: e["row"])
+    g1, g2 = dict_to_blob(exp[0]["value"]), dict_to_blob(exp[1]["value"])
+    whole = dict_to_blob(goldens["test_sum.py"]["tests"][0]["expected"][0]["value"])
+    # group 1 + group 2 == ungrouped (the reference's own literals on both sides)
+    np.testing.assert_array_equal(cofactor_hip.add(g1, g2), whole)
+    # and it agrees with the oracle's Value-level add (A12)
+    np.testing.assert_array_equal(cofactor_hip.add(g1, g2), orc.add(g1, g2))
+    # whole - group 2 has group 1's values on whole's key sets (zero counts stay, as sub.cpp keeps them)
+    d = blob_to_dict(cofactor_hip.sub(whole, g2))
+    assert d["N"] == 2 and d["lin_agg"] == blob_to_dict(g1)["lin_agg"]
+    np.testing.assert_array_equal(cofactor_hip.sub(whole, g2), orc.sub(whole, g2))
+
+
+def test_subtract_unknown_key_is_reported_not_fatal(goldens):
+    from triple_fmt import dict_to_blob
+    exp = sorted(goldens["test_sum.py"]["tests"][1]["expected"], key=lambda e: e["row"])
+    g1, g2 = dict_to_blob(exp[0]["value"]), dict_to_blob(exp[1]["value"])
+    out = cofactor_hip.sub(g1, g2)          # g2 has keys g1 lacks: reported and skipped
+    assert b"not present in first triple" in cofactor_hip.lib().cofactor_last_error()
+    np.testing.assert_array_equal(out, orc.sub(g1, g2))

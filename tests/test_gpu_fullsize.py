@@ -1,0 +1,82 @@
+"""Full-size (BASELINE.json configs) checks through size-independent properties: integer-valued
+tables whose exact sums torch can state in int64, and additivity over shards."""
+import numpy as np
+import pytest
+
+import cofactor_hip
+from triple_fmt import blob_to_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = cofactor_hip.Context(0)
+    yield c
+    c.close()
+
+
+def test_20_0_100M_rows_exact_on_integer_table(ctx):
+    """C2 size (1e8 rows x 20 float columns = 8 GB).  Values in 0..7, so every sum is an integer
+    below 2^53: the HIP result must equal torch's int64 sums exactly."""
+    import torch
+    rows, n = 100_000_000, 20
+    g = torch.Generator(device="cuda").manual_seed(42)
+    cols = [torch.randint(0, 8, (rows,), generator=g, device="cuda", dtype=torch.int32).float()
+            for _ in range(n)]
+    torch.cuda.synchronize()
+    agg = ctx.aggregate(n, 0)
+    agg.update_device(cols, [])
+    got = blob_to_dict(agg.finalize())
+    assert got["N"] == rows
+    ints = [c.to(torch.int32) for c in cols]
+    lin = [int(c.sum(dtype=torch.int64)) for c in ints]
+    assert got["lin_agg"] == [float(v) for v in lin]
+    q = 0
+    for j in range(n):
+        for k in range(j, n):
+            if (j * 7 + k) % 5 == 0 or j == k:           # a spread of 70-odd pairs
+                want = int((ints[j] * ints[k]).sum(dtype=torch.int64))
+                assert got["quad_agg"][q] == float(want), (j, k)
+            q += 1
+    # additivity: two shards sum to the whole, bit for bit on this table
+    a, b = ctx.aggregate(n, 0), ctx.aggregate(n, 0)
+    cut = 37_000_001
+    a.update_device_ptrs([c.data_ptr() for c in cols], [], cut)
+    b.update_device_ptrs([c.data_ptr() + 4 * cut for c in cols], [], rows - cut)   # 4-B aligned only
+    a.combine(b)
+    assert blob_to_dict(a.finalize()) == got
+    for x in (agg, a, b):
+        x.close()
+
+
+def test_10_10_100M_rows_counts_exact(ctx):
+    """C3 size (1e8 rows, 10 float + 10 int32 columns, 16 keys per column): key counts and pair
+    counts must equal torch.bincount exactly; per-key sums of 0..7-valued columns are exact too."""
+    import torch
+    rows, n, m, K = 100_000_000, 10, 10, 16
+    g = torch.Generator(device="cuda").manual_seed(7)
+    num = [torch.randint(0, 8, (rows,), generator=g, device="cuda", dtype=torch.int32).float()
+           for _ in range(n)]
+    cat = [torch.randint(0, K, (rows,), generator=g, device="cuda", dtype=torch.int32) for _ in range(m)]
+    torch.cuda.synchronize()
+    agg = ctx.aggregate(n, m)
+    agg.update_device(num, cat)
+    got = blob_to_dict(agg.finalize())
+    agg.close()
+    assert got["N"] == rows
+    for c in range(m):
+        cnt = torch.bincount(cat[c], minlength=K).cpu().tolist()
+        assert [e["key"] for e in got["lin_cat"][c]] == list(range(K))
+        assert [e["value"] for e in got["lin_cat"][c]] == [float(v) for v in cnt]
+    for (k, c) in [(0, 0), (3, 7), (9, 9), (5, 2)]:
+        s = torch.bincount(cat[c], weights=num[k].double(), minlength=K).cpu().tolist()
+        assert [e["value"] for e in got["quad_num_cat"][k * m + c]] == s
+    q = 0
+    for c1 in range(m):
+        for c2 in range(c1, m):
+            if (c1 + 3 * c2) % 4 == 0:
+                pc = torch.bincount(cat[c1].long() * K + cat[c2].long(), minlength=K * K).cpu().tolist()
+                want = [(a, b, float(pc[a * K + b])) for a in range(K) for b in range(K) if pc[a * K + b]]
+                assert [(e["key1"], e["key2"], e["value"]) for e in got["quad_cat"][q]] == want
+            q += 1
