@@ -19,6 +19,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = range(6
 SYMBOLS = [
     "cofactor_last_error", "cofactor_abi_version",
     "cofactor_ctx_create", "cofactor_ctx_destroy", "cofactor_ctx_synchronize", "cofactor_ctx_stream",
+    "cofactor_ctx_profile_enable", "cofactor_ctx_profile_read",
     "cofactor_agg_create", "cofactor_agg_destroy", "cofactor_agg_reset",
     "cofactor_agg_update_device", "cofactor_agg_update_host", "cofactor_agg_update_triples",
     "cofactor_agg_combine", "cofactor_agg_finalize",
@@ -41,6 +42,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise CofactorError(-1, "libcofactor_hip.so not built (run __graft_entry__.build())")
+        # torch ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both open
+        # the GPU.  Loading torch first makes the loader resolve our NEEDED libamdhip64.so.7 to
+        # the copy torch already mapped.  (C / C++ users link the system ROCm runtime as usual.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, pp, u64 = C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64
         pu64 = C.POINTER(C.c_uint64)
@@ -51,6 +59,8 @@ def lib():
         L.cofactor_ctx_synchronize.argtypes = [vp]
         L.cofactor_ctx_stream.argtypes = [vp]
         L.cofactor_ctx_stream.restype = vp
+        L.cofactor_ctx_profile_enable.argtypes = [vp, C.c_int]
+        L.cofactor_ctx_profile_read.argtypes = [vp, C.POINTER(C.c_double), pu64, C.POINTER(C.c_double), pu64]
         L.cofactor_agg_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, pp]
         L.cofactor_agg_destroy.argtypes = [vp]
         L.cofactor_agg_destroy.restype = None
@@ -114,6 +124,15 @@ class Context:
     def stream(self):
         """Raw hipStream_t of the context (an int)."""
         return lib().cofactor_ctx_stream(self._h)
+
+    def profile(self, on=True):
+        _check(lib().cofactor_ctx_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """-> dict(gram_ms, gram_launches, cat_ms, cat_launches) since the previous read."""
+        gm, cm, gl, cl = C.c_double(0), C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().cofactor_ctx_profile_read(self._h, C.byref(gm), C.byref(gl), C.byref(cm), C.byref(cl)))
+        return {"gram_ms": gm.value, "gram_launches": gl.value, "cat_ms": cm.value, "cat_launches": cl.value}
 
     def aggregate(self, n_num, n_cat, kind=TRIPLE):
         return Aggregate(self, n_num, n_cat, kind)

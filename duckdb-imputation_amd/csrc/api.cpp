@@ -56,6 +56,9 @@ struct cofactor_ctx {
   int cat_grid = 0;             // workgroups of the categorical kernel
   size_t lds_budget = 0;        // bytes of LDS one categorical workgroup may claim
   double *partials = nullptr;   // gram_grid * GRAM_ACC_LEN doubles
+  // optional HIP-event timing of the two streaming kernels (cofactor_ctx_profile_*)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev;
 };
 
 struct cofactor_agg {
@@ -215,7 +218,13 @@ cofactor_status cat_update(cofactor_agg *a, const NumCols &num, const CatCols &c
   }
   const size_t lds = cat_lds_bytes(a->L);
   const bool lds_tables = lds <= a->ctx->lds_budget;
-  HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, lds_tables, a->ctx->cat_grid, st));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (a->ctx->profiling) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    a->ctx->cat_ev.emplace_back(e0, e1);
+  }
+  HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, lds_tables, a->ctx->cat_grid, st, e0, e1));
   a->cat_check_pending = true;                    // flags[1] is looked at by the next snapshot
   return COFACTOR_OK;
 }
@@ -224,8 +233,15 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
                                    uint64_t rows) {
   if (rows == 0) return COFACTOR_OK;
   cofactor_ctx *ctx = a->ctx;
-  if (a->n > 0)
-    HIP_TRY(launch_gram(num, a->n, rows, ctx->gram_grid, ctx->partials, a->d_acc, ctx->stream));
+  if (a->n > 0) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->profiling) {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      ctx->gram_ev.emplace_back(e0, e1);
+    }
+    HIP_TRY(launch_gram(num, a->n, rows, ctx->gram_grid, ctx->partials, a->d_acc, ctx->stream, e0, e1));
+  }
   if (a->m > 0) {
     cofactor_status s = cat_update(a, num, cat, rows);
     if (s != COFACTOR_OK) return s;
@@ -384,6 +400,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)cofactor_ctx_profile_read(ctx, nullptr, nullptr, nullptr, nullptr);
   (void)hipFree(ctx->partials);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -397,6 +414,34 @@ cofactor_status cofactor_ctx_synchronize(cofactor_ctx *ctx) {
 }
 
 void *cofactor_ctx_stream(cofactor_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+cofactor_status cofactor_ctx_profile_enable(cofactor_ctx *ctx, int on) {
+  if (!ctx) return fail(COFACTOR_ERR_INVALID, "ctx is null");
+  ctx->profiling = on != 0;
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms, uint64_t *gram_launches,
+                                          double *cat_ms, uint64_t *cat_launches) {
+  if (!ctx) return fail(COFACTOR_ERR_INVALID, "ctx is null");
+  DeviceGuard guard(ctx->device);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>> &evs, double *ms, uint64_t *cnt) {
+    double total = 0;
+    for (auto &p : evs) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) total += t;
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+    if (ms) *ms = total;
+    if (cnt) *cnt = evs.size();
+    evs.clear();
+  };
+  drain(ctx->gram_ev, gram_ms, gram_launches);
+  drain(ctx->cat_ev, cat_ms, cat_launches);
+  return COFACTOR_OK;
+}
 
 cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cofactor_kind kind,
                                     cofactor_agg **out) {

@@ -258,7 +258,7 @@ hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, con
 
 hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
                                  const CatLayout &L, const CatDevice &D, bool lds_tables, int grid,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (rows == 0 || L.m == 0) return hipSuccess;
   const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
   if ((uint64_t)grid > need) grid = (int)need;
@@ -273,10 +273,14 @@ hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_
     hipLaunchKernelGGL((cat_accumulate_kernel<LT, K>), dim3(grid), dim3(CAT_THREADS), lds,        \
                        stream, num, cat, rows, L, D);                                             \
   } while (0)
+  if (ev0) { hipError_t e = hipEventRecord(ev0, stream); if (e != hipSuccess) return e; }
   if (lds_tables) { if (L.kind == 0) GO(true, 0); else GO(true, 1); }
   else { if (L.kind == 0) GO(false, 0); else GO(false, 1); }
 #undef GO
-  return hipGetLastError();
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return le;
+  if (ev1) return hipEventRecord(ev1, stream);
+  return hipSuccess;
 }
 
 }  // namespace cofactor

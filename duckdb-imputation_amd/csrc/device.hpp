@@ -39,8 +39,10 @@ __host__ __device__ inline int gram_lin_pos(int c, int n) {
 
 // Launches the Gram pass over `rows` rows of n columns and adds the result into acc[GRAM_ACC_LEN]
 // (device doubles).  partials must hold grid * GRAM_ACC_LEN doubles.
+// ev0 / ev1 (optional) are recorded on `stream` right before / after the Gram kernel itself.
 hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
-                       double *acc, hipStream_t stream);
+                       double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                       hipEvent_t ev1 = nullptr);
 
 // ---- categorical tables -----------------------------------------------------------------------
 constexpr int MAX_PAIRS = COFACTOR_MAX_CAT * (COFACTOR_MAX_CAT + 1) / 2;
@@ -74,7 +76,8 @@ hipError_t launch_cat_insert(const CatCols &cols, uint64_t rows, const CatLayout
 hipError_t launch_cat_assign_codes(const CatLayout &L, const CatDevice &D, hipStream_t stream);
 hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
                                  const CatLayout &L, const CatDevice &D, bool lds_tables, int grid,
-                                 hipStream_t stream);
+                                 hipStream_t stream, hipEvent_t ev0 = nullptr,
+                                 hipEvent_t ev1 = nullptr);
 // re-inserts every (key, code) of the old dictionary into the new one (dictionary growth)
 hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
                              const CatDevice &Dnew, hipStream_t stream);

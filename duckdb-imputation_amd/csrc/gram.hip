@@ -190,11 +190,12 @@ hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partia
 }  // namespace
 
 hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
-                       double *acc, hipStream_t stream) {
+                       double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (rows == 0 || n == 0) return hipSuccess;
   const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
   if ((uint64_t)grid > ntiles) grid = (int)ntiles;
   hipError_t e = hipErrorInvalidValue;
+  if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
   switch (n) {
 #define CASE(N) case N: e = launch_n<N>(cols, rows, grid, partials, stream); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
@@ -203,6 +204,7 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
+  if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
   hipLaunchKernelGGL(gram_fold_kernel, dim3(GRAM_ACC_LEN), dim3(256), 0, stream, partials, grid, acc);
   return hipGetLastError();
 }

@@ -71,6 +71,14 @@ cofactor_status cofactor_ctx_synchronize(cofactor_ctx *ctx);
 /* The hipStream_t all of this context's kernels are launched on (for event timing). */
 void *cofactor_ctx_stream(cofactor_ctx *ctx);
 
+/* Optional timing of the two streaming kernels with HIP events recorded on the context stream
+ * right around each launch (bench.py's roofline figures).  read synchronises the stream, returns
+ * the summed kernel milliseconds and launch counts since the previous read, and clears them. */
+cofactor_status cofactor_ctx_profile_enable(cofactor_ctx *ctx, int on);
+cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms,
+                                          uint64_t *gram_launches, double *cat_ms,
+                                          uint64_t *cat_launches);
+
 /* ---- aggregate state ------------------------------------------------------------------------
  * Replaces Triple::SumState + StateFunction::Initialize/Destroy
  * (duckdb_extension/src/include/triple/sum/sum_state.h:14-57).  n/m are what the reference
