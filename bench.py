@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--num-cols", type=int, default=20)
     ap.add_argument("--cat-cols", type=int, default=0)
     ap.add_argument("--keys", type=int, default=16, help="distinct keys per categorical column")
-    ap.add_argument("--cpu-sample-rows", type=float, default=2e7)
+    ap.add_argument("--cpu-sample-rows", type=float, default=6e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
