@@ -77,6 +77,7 @@ def main():
     import torch.distributed as dist
 
     import cofactor_hip
+    from cofactor_hip import dist as cdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +95,6 @@ def main():
     num, cat = make_table(torch, rows, n, m, args.keys, device, seed=42 + rank)
     ctx = cofactor_hip.Context(local_rank)
     agg = ctx.aggregate(n, m)
-    dense = torch.zeros(agg.dense_len(), dtype=torch.float64, device=device)
     num_ptrs = [t.data_ptr() for t in num]
     cat_ptrs = [t.data_ptr() for t in cat]
     torch.cuda.synchronize()
@@ -103,10 +103,8 @@ def main():
         agg.reset()
         agg.update_device_ptrs(num_ptrs, cat_ptrs, rows)
         if world > 1:
-            agg.export_dense_device(dense.data_ptr())     # waits for the kernels of this rank
-            dist.all_reduce(dense)                        # ONE RCCL all-reduce of the partial triple
-            torch.cuda.synchronize()
-            agg.import_dense_device(dense.data_ptr())
+            # ONE RCCL all-reduce of the dense partial triple (+ host merge of categorical lists)
+            return cdist.allreduce_triple(agg, dist, device)
         return agg.finalize()
 
     def fence():

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcofactor_hip.so")
+LIB_PATH = os.environ.get("COFACTOR_LIB", os.path.join(_HERE, "libcofactor_hip.so"))
 
 TRIPLE, NB = 0, 1
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)

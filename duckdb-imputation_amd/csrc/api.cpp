@@ -218,6 +218,13 @@ cofactor_status cat_update(cofactor_agg *a, const NumCols &num, const CatCols &c
   }
   const size_t lds = cat_lds_bytes(a->L);
   const bool lds_tables = lds <= a->ctx->lds_budget;
+#ifdef COFACTOR_DEV_ABLATE
+  {
+    int32_t mask = (int32_t)env_long("COFACTOR_CAT_ABLATE", 0);
+    HIP_TRY(hipMemcpyAsync(a->D.flags + 2, &mask, sizeof(mask), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+#endif
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (a->ctx->profiling) {
     HIP_TRY(hipEventCreate(&e0));

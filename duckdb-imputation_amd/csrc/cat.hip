@@ -124,7 +124,9 @@ __device__ __forceinline__ int lookup_code(SlotPtr slots, CodePtr codes, int cap
   return -1;
 }
 
-template <bool LDS_TABLES, int KIND>
+// MT > 0: the number of categorical columns is the compile-time constant MT (straight-line
+// atomics, no per-column branches); MT == 0: generic variant that reads m from the layout.
+template <bool LDS_TABLES, int KIND, int MT>
 __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num, CatCols cat,
                                                                      uint64_t rows, CatLayout L,
                                                                      CatDevice D) {
@@ -135,6 +137,8 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
   int32_t *l_code = reinterpret_cast<int32_t *>(l_s + (KIND == 0 ? L.n_s : 0));
   unsigned *l_cnt = reinterpret_cast<unsigned *>(l_code + L.n_slots);
   unsigned *l_p = l_cnt + L.n_cnt;
+  constexpr int MC = MT > 0 ? MT : COFACTOR_MAX_CAT;       // unroll bound
+  const int m = MT > 0 ? MT : L.m;
 
   const int tid = threadIdx.x;
   if (LDS_TABLES) {
@@ -147,51 +151,69 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
     __syncthreads();
   }
 
+#ifdef COFACTOR_DEV_ABLATE   // timing experiments only (results are wrong when a bit is set)
+  const int ablate = D.flags[2];
+#else
+  constexpr int ablate = 0;
+#endif
+  const int n = L.n;
   const uint64_t stride = (uint64_t)gridDim.x * CAT_THREADS;
   for (uint64_t r = (uint64_t)blockIdx.x * CAT_THREADS + tid; r < rows; r += stride) {
-    int code[COFACTOR_MAX_CAT];
+    int32_t key[MC];
 #pragma unroll
-    for (int c = 0; c < COFACTOR_MAX_CAT; c++) {
-      if (c < L.m) {
-        const int32_t key = cat.p[c][r];
-        if (LDS_TABLES) code[c] = lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], key);
-        else code[c] = lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], key);
-      }
-    }
+    for (int c = 0; c < MC; c++)
+      if (c < m) key[c] = cat.p[c][r];                      // all loads first, then the probes
+    float xk = (KIND == 0 && n > 0) ? num.p[0][r] : 0.f;
+    int code[MC];
     bool known = true;
 #pragma unroll
-    for (int c = 0; c < COFACTOR_MAX_CAT; c++)
-      if (c < L.m) known = known && code[c] >= 0 && code[c] < L.kc[c];
-    if (!known) { D.flags[1] = 1; continue; }     // never index a table with a bad code
+    for (int c = 0; c < MC; c++) {
+      if (c < m) {
+        if (LDS_TABLES) code[c] = lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], key[c]);
+        else code[c] = lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], key[c]);
+        known = known && code[c] >= 0 && code[c] < L.kc[c];
+      }
+    }
+    if (!known) { D.flags[1] = 1; continue; }               // never index a table with a bad code
+    if (!(ablate & 1)) {
 #pragma unroll
-    for (int c = 0; c < COFACTOR_MAX_CAT; c++) {
-      if (c < L.m) {
-        if (LDS_TABLES) atomicAdd(&l_cnt[L.cnt_off[c] + code[c]], 1u);
-        else atomicAdd(&D.cnt[L.cnt_off[c] + code[c]], 1ull);
+      for (int c = 0; c < MC; c++) {
+        if (c < m) {
+          if (LDS_TABLES) atomicAdd(&l_cnt[L.cnt_off[c] + code[c]], 1u);
+          else atomicAdd(&D.cnt[L.cnt_off[c] + code[c]], 1ull);
+        }
       }
     }
     if (KIND == 0) {
-      for (int k = 0; k < L.n; k++) {
-        const double x = (double)num.p[k][r];
+      if (!(ablate & 4)) {
+        int q = 0;
 #pragma unroll
-        for (int c = 0; c < COFACTOR_MAX_CAT; c++) {
-          if (c < L.m) {
-            const int idx = L.s_off[c] + code[c] * L.n + k;
-            if (LDS_TABLES) unsafeAtomicAdd(&l_s[idx], x);
-            else unsafeAtomicAdd(&D.s[idx], x);
+        for (int c1 = 0; c1 < MC; c1++) {
+#pragma unroll
+          for (int c2 = c1; c2 < MC; c2++) {
+            if (c2 < m) {
+              const int idx = L.p_off[q] + code[c1] * L.kc[c2] + code[c2];
+              if (LDS_TABLES) atomicAdd(&l_p[idx], 1u);
+              else atomicAdd(&D.p[idx], 1ull);
+              q++;
+            }
           }
         }
       }
-      int q = 0;
+      if (!(ablate & 2)) {
+        int sidx[MC];
 #pragma unroll
-      for (int c1 = 0; c1 < COFACTOR_MAX_CAT; c1++) {
+        for (int c = 0; c < MC; c++)
+          if (c < m) sidx[c] = L.s_off[c] + code[c] * n;
+        for (int k = 0; k < n; k++) {
+          const double x = (double)xk;
+          if (k + 1 < n) xk = num.p[k + 1][r];              // next column's value flies under the adds
 #pragma unroll
-        for (int c2 = c1; c2 < COFACTOR_MAX_CAT; c2++) {
-          if (c2 < L.m) {
-            const int idx = L.p_off[q] + code[c1] * L.kc[c2] + code[c2];
-            if (LDS_TABLES) atomicAdd(&l_p[idx], 1u);
-            else atomicAdd(&D.p[idx], 1ull);
-            q++;
+          for (int c = 0; c < MC; c++) {
+            if (c < m) {
+              if (LDS_TABLES) unsafeAtomicAdd(&l_s[sidx[c] + k], x);
+              else unsafeAtomicAdd(&D.s[sidx[c] + k], x);
+            }
           }
         }
       }
@@ -208,6 +230,32 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
       for (int i = tid; i < L.n_p; i += CAT_THREADS)
         if (l_p[i]) atomicAdd(&D.p[i], (unsigned long long)l_p[i]);
     }
+  }
+}
+
+template <bool LT, int K, int MT>
+hipError_t launch_acc(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
+                      const CatDevice &D, int grid, size_t lds, hipStream_t stream) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)cat_accumulate_kernel<LT, K, MT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((cat_accumulate_kernel<LT, K, MT>), dim3(grid), dim3(CAT_THREADS), lds, stream,
+                     num, cat, rows, L, D);
+  return hipGetLastError();
+}
+
+template <int K>
+hipError_t launch_acc_lds(int m, const NumCols &num, const CatCols &cat, uint64_t rows,
+                          const CatLayout &L, const CatDevice &D, int grid, size_t lds,
+                          hipStream_t stream) {
+  switch (m) {
+#define CASE(M) case M: return launch_acc<true, K, M>(num, cat, rows, L, D, grid, lds, stream);
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+    CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
+#undef CASE
+    default: return hipErrorInvalidValue;
   }
 }
 
@@ -263,21 +311,15 @@ hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_
   const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
   if ((uint64_t)grid > need) grid = (int)need;
   const size_t lds = lds_tables ? cat_lds_bytes(L) : 0;
-#define GO(LT, K)                                                                                 \
-  do {                                                                                            \
-    if (lds > 48 * 1024) {                                                                        \
-      hipError_t e = hipFuncSetAttribute((const void *)cat_accumulate_kernel<LT, K>,              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-      if (e != hipSuccess) return e;                                                              \
-    }                                                                                             \
-    hipLaunchKernelGGL((cat_accumulate_kernel<LT, K>), dim3(grid), dim3(CAT_THREADS), lds,        \
-                       stream, num, cat, rows, L, D);                                             \
-  } while (0)
   if (ev0) { hipError_t e = hipEventRecord(ev0, stream); if (e != hipSuccess) return e; }
-  if (lds_tables) { if (L.kind == 0) GO(true, 0); else GO(true, 1); }
-  else { if (L.kind == 0) GO(false, 0); else GO(false, 1); }
-#undef GO
-  hipError_t le = hipGetLastError();
+  hipError_t le;
+  if (lds_tables) {
+    le = L.kind == 0 ? launch_acc_lds<0>(L.m, num, cat, rows, L, D, grid, lds, stream)
+                     : launch_acc_lds<1>(L.m, num, cat, rows, L, D, grid, lds, stream);
+  } else {
+    le = L.kind == 0 ? launch_acc<false, 0, 0>(num, cat, rows, L, D, grid, 0, stream)
+                     : launch_acc<false, 1, 0>(num, cat, rows, L, D, grid, 0, stream);
+  }
   if (le != hipSuccess) return le;
   if (ev1) return hipEventRecord(ev1, stream);
   return hipSuccess;
