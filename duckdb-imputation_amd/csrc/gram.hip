@@ -18,9 +18,12 @@
 //     adds them, in a fixed order, into the aggregate's accumulator image.
 #include "device.hpp"
 
+#include <cstdlib>
+
 namespace cofactor {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -42,6 +45,10 @@ __device__ __forceinline__ float4 load_rows4_tail(const float *__restrict__ col,
   if (row + 3 < rows) v.w = col[row + 3];
   return v;
 }
+
+#ifdef COFACTOR_DEV_ABLATE
+__device__ int g_gram_ablate = 0;   // timing experiments only: 1 = no MFMA loop, 2 = loads only
+#endif
 
 template <int N, bool ALIGNED>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64_t rows,
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   };
 
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-  float ls = 0.f;
+  f32x2 ls_lo = {0.f, 0.f}, ls_hi = {0.f, 0.f};         // per-lane column sums of the A operand
   double dq0 = 0, dq1 = 0, dq2 = 0, dq3 = 0, dl = 0;
   const float *pa = tile + colA * CS + wave * 64;
   const float *pb = tile + colB * CS + wave * 64;
@@ -106,29 +113,48 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   uint64_t t = blockIdx.x;
   if (t < ntiles) fetch(t);
   int since_flush = 0;
+#ifdef COFACTOR_DEV_ABLATE
+  const int ablate = g_gram_ablate;
+#endif
   while (t < ntiles) {
+#ifdef COFACTOR_DEV_ABLATE
+    if (ablate == 2) {
+      for (int i = 0; i < LD; i++) asm volatile("" ::"v"(pre[i].x), "v"(pre[i].y), "v"(pre[i].z), "v"(pre[i].w));
+      const uint64_t tn2 = t + gridDim.x;
+      if (tn2 < ntiles) fetch(tn2);
+      t = tn2;
+      continue;
+    }
+#endif
     park();
     __syncthreads();
     const uint64_t tn = t + gridDim.x;
     if (tn < ntiles) fetch(tn);                   // next tile's loads fly under this tile's MFMAs
+#ifdef COFACTOR_DEV_ABLATE
+    if (ablate == 1) { __syncthreads(); t = tn; continue; }
+#endif
+    {
+      const f32x4 *va = reinterpret_cast<const f32x4 *>(pa);
+      const f32x4 *vb = reinterpret_cast<const f32x4 *>(pb);
 #pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-      const float4 a = *reinterpret_cast<const float4 *>(pa + 4 * it);
-      const float4 b = *reinterpret_cast<const float4 *>(pb + 4 * it);
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b.z, acc2, 0, 0, 0);
-      acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b.w, acc3, 0, 0, 0);
-      ls += (a.x + a.y) + (a.z + a.w);
+      for (int it = 0; it < 16; it++) {
+        const f32x4 a = va[it], b = vb[it];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc3, 0, 0, 0);
+        ls_lo += __builtin_shufflevector(a, a, 0, 1);       // v_pk_add_f32 on the aligned halves
+        ls_hi += __builtin_shufflevector(a, a, 2, 3);
+      }
     }
     if (++since_flush == FLUSH_TILES) {
       dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
       dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
       dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
       dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
-      dl += (double)ls;
+      dl += (double)((ls_lo[0] + ls_lo[1]) + (ls_hi[0] + ls_hi[1]));
       acc0 = acc1 = acc2 = acc3 = f32x4{0, 0, 0, 0};
-      ls = 0.f;
+      ls_lo = ls_hi = f32x2{0.f, 0.f};
       since_flush = 0;
     }
     __syncthreads();                              // everyone done reading before the next park()
@@ -138,7 +164,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
   dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
   dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
-  dl += (double)ls;
+  dl += (double)((ls_lo[0] + ls_lo[1]) + (ls_hi[0] + ls_hi[1]));
 
   // fold the 4 waves (fixed order) through LDS, then one image per workgroup
   double *red = reinterpret_cast<double *>(tile);  // 4 waves x 320 doubles = 10 KiB
@@ -192,6 +218,14 @@ hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partia
 hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
                        double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (rows == 0 || n == 0) return hipSuccess;
+#ifdef COFACTOR_DEV_ABLATE
+  {
+    const char *v = getenv("COFACTOR_GRAM_ABLATE");
+    int mask = v ? atoi(v) : 0;
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_ablate), &mask, sizeof(int), 0, hipMemcpyHostToDevice, stream);
+    (void)hipStreamSynchronize(stream);
+  }
+#endif
   const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
   if ((uint64_t)grid > ntiles) grid = (int)ntiles;
   hipError_t e = hipErrorInvalidValue;
