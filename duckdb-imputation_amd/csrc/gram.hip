@@ -25,14 +25,20 @@ namespace cofactor {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+
 namespace {
 
 constexpr int FLUSH_TILES = 4;  // 4 tiles x 16 rows per chain = 64 fp32 adds between fp64 folds
 
 template <bool ALIGNED>
 __device__ __forceinline__ float4 load_rows4_full(const float *__restrict__ col, uint64_t row) {
-  if (ALIGNED) return *reinterpret_cast<const float4 *>(col + row);
-  return make_float4(col[row], col[row + 1], col[row + 2], col[row + 3]);
+  // every byte is read exactly once: non-temporal loads keep the stream from churning L2 / MALL
+  if (ALIGNED) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(col + row));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+  return make_float4(__builtin_nontemporal_load(col + row), __builtin_nontemporal_load(col + row + 1),
+                     __builtin_nontemporal_load(col + row + 2), __builtin_nontemporal_load(col + row + 3));
 }
 
 // last, partial tile only: rows past the end contribute zeros (neutral for every sum)
