@@ -138,12 +138,10 @@ def main():
 
     if rank == 0:
         bytes_per_row = 4 * (n + m)
-        if m == 0 or prof["gram_ms"] >= prof["cat_ms"]:
-            kname, kms, kl = "gram_kernel", prof["gram_ms"], prof["gram_launches"]
-            kbytes = 4 * n * rows
-        else:
-            kname, kms, kl = "cat_accumulate_kernel", prof["cat_ms"], prof["cat_launches"]
-            kbytes = bytes_per_row * rows
+        cands = [("gram_kernel", prof["gram_ms"], prof["gram_launches"], 4 * n * rows),
+                 ("cat_accumulate_kernel", prof["cat_ms"], prof["cat_launches"], bytes_per_row * rows),
+                 ("fused_kernel", prof["fused_ms"], prof["fused_launches"], bytes_per_row * rows)]
+        kname, kms, kl, kbytes = max(cands, key=lambda c: c[1])       # the dominant kernel
         avg_ms = kms / max(1, kl)
         achieved = kbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None

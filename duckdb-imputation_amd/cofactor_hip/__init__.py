@@ -60,7 +60,7 @@ def lib():
         L.cofactor_ctx_stream.argtypes = [vp]
         L.cofactor_ctx_stream.restype = vp
         L.cofactor_ctx_profile_enable.argtypes = [vp, C.c_int]
-        L.cofactor_ctx_profile_read.argtypes = [vp, C.POINTER(C.c_double), pu64, C.POINTER(C.c_double), pu64]
+        L.cofactor_ctx_profile_read.argtypes = [vp] + [C.POINTER(C.c_double), pu64] * 3
         L.cofactor_agg_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, pp]
         L.cofactor_agg_destroy.argtypes = [vp]
         L.cofactor_agg_destroy.restype = None
@@ -129,10 +129,15 @@ class Context:
         _check(lib().cofactor_ctx_profile_enable(self._h, int(on)))
 
     def profile_read(self):
-        """-> dict(gram_ms, gram_launches, cat_ms, cat_launches) since the previous read."""
-        gm, cm, gl, cl = C.c_double(0), C.c_double(0), C.c_uint64(0), C.c_uint64(0)
-        _check(lib().cofactor_ctx_profile_read(self._h, C.byref(gm), C.byref(gl), C.byref(cm), C.byref(cl)))
-        return {"gram_ms": gm.value, "gram_launches": gl.value, "cat_ms": cm.value, "cat_launches": cl.value}
+        """-> dict({gram,cat,fused}_ms, {gram,cat,fused}_launches) since the previous read."""
+        ms = [C.c_double(0) for _ in range(3)]
+        ln = [C.c_uint64(0) for _ in range(3)]
+        _check(lib().cofactor_ctx_profile_read(self._h, C.byref(ms[0]), C.byref(ln[0]), C.byref(ms[1]),
+                                               C.byref(ln[1]), C.byref(ms[2]), C.byref(ln[2])))
+        out = {}
+        for name, a, b in zip(("gram", "cat", "fused"), ms, ln):
+            out[name + "_ms"], out[name + "_launches"] = a.value, b.value
+        return out
 
     def aggregate(self, n_num, n_cat, kind=TRIPLE):
         return Aggregate(self, n_num, n_cat, kind)

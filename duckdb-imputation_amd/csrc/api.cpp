@@ -56,9 +56,13 @@ struct cofactor_ctx {
   int cat_grid = 0;             // workgroups of the categorical kernel
   size_t lds_budget = 0;        // bytes of LDS one categorical workgroup may claim
   double *partials = nullptr;   // gram_grid * GRAM_ACC_LEN doubles
+  unsigned *pair_slabs = nullptr;   // fused kernel: one u32 pair table per workgroup
+  size_t pair_slab_bytes = 0;
   // optional HIP-event timing of the two streaming kernels (cofactor_ctx_profile_*)
   bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev, fused_ev;
+  bool allow_fused = true;      // COFACTOR_NO_FUSED=1 forces the two-kernel path
+  size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
 };
 
 struct cofactor_agg {
@@ -70,6 +74,7 @@ struct cofactor_agg {
   // categorical device state
   bool cat_ready = false;
   bool cat_check_pending = false;
+  int32_t nkeys_host[COFACTOR_MAX_CAT] = {0};
   CatLayout L{};
   CatDevice D{};
   // host staging for update_host (pinned) and its device mirror
@@ -175,8 +180,10 @@ cofactor_status cat_prepare(cofactor_agg *a) {
   return COFACTOR_OK;
 }
 
-// The categorical half of one device update.
-cofactor_status cat_update(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows) {
+// Dictionary maintenance for one batch: find unseen keys, give them codes, grow the dictionaries
+// and code-indexed tables when a column outgrew them.  Leaves the per-column key counts in
+// a->nkeys_host.
+cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t rows) {
   cofactor_status s = cat_prepare(a);
   if (s != COFACTOR_OK) return s;
   hipStream_t st = a->ctx->stream;
@@ -205,6 +212,7 @@ cofactor_status cat_update(cofactor_agg *a, const NumCols &num, const CatCols &c
   bool grow = false;
   CatLayout Ln = a->L;
   for (int c = 0; c < a->m; c++) {
+    a->nkeys_host[c] = counters[c];
     if (counters[c] > Ln.kc[c]) { Ln.kc[c] = next_pow2(counters[c]); grow = true; }
     while (counters[c] * 2 > Ln.ht_cap[c]) { Ln.ht_cap[c] *= 2; grow = true; }  // load factor <= 1/2
   }
@@ -216,6 +224,11 @@ cofactor_status cat_update(cofactor_agg *a, const NumCols &num, const CatCols &c
     s = cat_regrow(a, Ln);
     if (s != COFACTOR_OK) return s;
   }
+  return COFACTOR_OK;
+}
+
+cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows) {
+  hipStream_t st = a->ctx->stream;
   const size_t lds = cat_lds_bytes(a->L);
   const bool lds_tables = lds <= a->ctx->lds_budget;
 #ifdef COFACTOR_DEV_ABLATE
@@ -232,7 +245,6 @@ cofactor_status cat_update(cofactor_agg *a, const NumCols &num, const CatCols &c
     a->ctx->cat_ev.emplace_back(e0, e1);
   }
   HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, lds_tables, a->ctx->cat_grid, st, e0, e1));
-  a->cat_check_pending = true;                    // flags[1] is looked at by the next snapshot
   return COFACTOR_OK;
 }
 
@@ -240,19 +252,55 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
                                    uint64_t rows) {
   if (rows == 0) return COFACTOR_OK;
   cofactor_ctx *ctx = a->ctx;
-  if (a->n > 0) {
+  hipStream_t st = ctx->stream;
+  bool fused = false;
+  if (a->m > 0) {
+    cofactor_status s = cat_dictionaries(a, cat, rows);
+    if (s != COFACTOR_OK) return s;
+    fused = ctx->allow_fused && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
+  }
+#ifdef COFACTOR_DEV_ABLATE
+  if (a->m > 0) {
+    int32_t mask = (int32_t)env_long("COFACTOR_CAT_ABLATE", 0);
+    HIP_TRY(hipMemcpyAsync(a->D.flags + 2, &mask, sizeof(mask), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+#endif
+  if (fused) {                                    // one pass: dense + categorical
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profiling) {
       HIP_TRY(hipEventCreate(&e0));
       HIP_TRY(hipEventCreate(&e1));
-      ctx->gram_ev.emplace_back(e0, e1);
+      ctx->fused_ev.emplace_back(e0, e1);
     }
-    HIP_TRY(launch_gram(num, a->n, rows, ctx->gram_grid, ctx->partials, a->d_acc, ctx->stream, e0, e1));
+    const int grid = fused_grid(a->L, ctx->cus, ctx->gram_grid, rows);
+    const size_t slab = fused_slab_bytes(a->L, grid);
+    if (slab > ctx->pair_slab_bytes) {            // grow the per-workgroup pair slabs
+      HIP_TRY(hipStreamSynchronize(st));
+      (void)hipFree(ctx->pair_slabs);
+      ctx->pair_slabs = nullptr;
+      ctx->pair_slab_bytes = 0;
+      HIP_TRY(hipMalloc((void **)&ctx->pair_slabs, slab));
+      ctx->pair_slab_bytes = slab;
+    }
+    HIP_TRY(launch_fused(num, cat, rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, a->d_acc, st,
+                         e0, e1));
+  } else {
+    if (a->n > 0) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (ctx->profiling) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        ctx->gram_ev.emplace_back(e0, e1);
+      }
+      HIP_TRY(launch_gram(num, a->n, rows, ctx->gram_grid, ctx->partials, a->d_acc, st, e0, e1));
+    }
+    if (a->m > 0) {
+      cofactor_status s = cat_accumulate(a, num, cat, rows);
+      if (s != COFACTOR_OK) return s;
+    }
   }
-  if (a->m > 0) {
-    cofactor_status s = cat_update(a, num, cat, rows);
-    if (s != COFACTOR_OK) return s;
-  }
+  if (a->m > 0) a->cat_check_pending = true;      // flags[1] is looked at by the next snapshot
   a->dev_rows += (double)rows;
   return COFACTOR_OK;
 }
@@ -396,8 +444,9 @@ cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   ctx->gram_grid = (int)env_long("COFACTOR_GRAM_WGS_PER_CU", 4) * ctx->cus;
   ctx->cat_grid = (int)env_long("COFACTOR_CAT_WGS_PER_CU", 2) * ctx->cus;
   ctx->lds_budget = (size_t)env_long("COFACTOR_CAT_LDS_BYTES", 150 * 1024);
-  if (ctx->lds_budget > prop.sharedMemPerBlock && prop.sharedMemPerBlock > 0)
-    ctx->lds_budget = prop.sharedMemPerBlock;
+  if (prop.sharedMemPerBlock > 0) ctx->lds_max = prop.sharedMemPerBlock;
+  if (ctx->lds_budget > ctx->lds_max) ctx->lds_budget = ctx->lds_max;
+  ctx->allow_fused = env_long("COFACTOR_NO_FUSED", 0) == 0;
   HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)ctx->gram_grid * GRAM_ACC_LEN));
   *out = ctx.release();
   return COFACTOR_OK;
@@ -407,8 +456,9 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)cofactor_ctx_profile_read(ctx, nullptr, nullptr, nullptr, nullptr);
+  (void)cofactor_ctx_profile_read(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   (void)hipFree(ctx->partials);
+  (void)hipFree(ctx->pair_slabs);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -429,7 +479,8 @@ cofactor_status cofactor_ctx_profile_enable(cofactor_ctx *ctx, int on) {
 }
 
 cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms, uint64_t *gram_launches,
-                                          double *cat_ms, uint64_t *cat_launches) {
+                                          double *cat_ms, uint64_t *cat_launches, double *fused_ms,
+                                          uint64_t *fused_launches) {
   if (!ctx) return fail(COFACTOR_ERR_INVALID, "ctx is null");
   DeviceGuard guard(ctx->device);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -447,6 +498,7 @@ cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms, ui
   };
   drain(ctx->gram_ev, gram_ms, gram_launches);
   drain(ctx->cat_ev, cat_ms, cat_launches);
+  drain(ctx->fused_ev, fused_ms, fused_launches);
   return COFACTOR_OK;
 }
 

@@ -30,27 +30,82 @@ __device__ __forceinline__ unsigned long long pack_key(int32_t key) {
   return (1ull << 32) | (unsigned long long)(unsigned)key;
 }
 
+__device__ __forceinline__ void dict_insert(unsigned long long *slots, int cap, int32_t key, int32_t *flags) {
+  const unsigned long long want = pack_key(key);
+  unsigned h = hash_key(key, cap);
+  for (int probe = 0; probe < cap; probe++) {
+    const unsigned long long cur = slots[h];
+    if (cur == want) return;
+    if (cur == 0ull) {
+      const unsigned long long old = atomicCAS(&slots[h], 0ull, want);
+      if (old == 0ull || old == want) return;
+    }
+    h = (h + 1) & (cap - 1);
+  }
+  flags[0] = 1;                                   // dictionary full: host grows it and re-runs
+}
+
+// Four rows per thread, 16-B loads per column when the column is 16-B aligned.  The dictionaries
+// as they stand at launch are copied to LDS (when lds_slots > 0) and a key found there costs one
+// LDS probe; only keys missing from that snapshot go to the global table (CAS insert).
 __global__ __launch_bounds__(256) void cat_insert_kernel(CatCols cols, uint64_t rows, CatLayout L,
-                                                         CatDevice D) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
-    for (int c = 0; c < L.m; c++) {
-      const int32_t key = cols.p[c][r];
-      const unsigned long long want = pack_key(key);
-      const int cap = L.ht_cap[c];
-      unsigned long long *slots = D.ht_slot + L.ht_off[c];
-      unsigned h = hash_key(key, cap);
-      int probe = 0;
-      for (; probe < cap; probe++) {
-        unsigned long long cur = slots[h];
-        if (cur == want) break;
-        if (cur == 0ull) {
-          const unsigned long long old = atomicCAS(&slots[h], 0ull, want);
-          if (old == 0ull || old == want) break;
+                                                         CatDevice D, int lds_slots) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned long long *l_slot = reinterpret_cast<unsigned long long *>(lds_raw);
+  for (int i = threadIdx.x; i < lds_slots; i += blockDim.x) l_slot[i] = D.ht_slot[i];
+  if (lds_slots) __syncthreads();
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  constexpr int CH = 10;                          // columns whose loads are issued together
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
+  for (uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; r < rows; r += stride) {
+    const bool whole = r + 4 <= rows;
+    const int cnt = whole ? 4 : (int)(rows - r);
+    for (int c0 = 0; c0 < L.m; c0 += CH) {
+      i32x4 kv[CH];
+#pragma unroll
+      for (int j = 0; j < CH; j++) {              // all loads of the chunk first: bytes in flight
+        const int c = c0 + j;
+        if (c < L.m) {
+          const int32_t *col = cols.p[c];
+          if (whole && (reinterpret_cast<uintptr_t>(col) & 15) == 0) {
+            kv[j] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(col + r));
+          } else {
+            i32x4 v = {0, 0, 0, 0};
+            if (cnt > 0) v[0] = col[r];
+            if (cnt > 1) v[1] = col[r + 1];
+            if (cnt > 2) v[2] = col[r + 2];
+            if (cnt > 3) v[3] = col[r + 3];
+            kv[j] = v;
+          }
         }
-        h = (h + 1) & (cap - 1);
       }
-      if (probe == cap) D.flags[0] = 1;           // dictionary full: host grows it and re-runs
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const int c = c0 + j;
+        if (c < L.m) {
+          unsigned long long *slots = D.ht_slot + L.ht_off[c];
+          const int cap = L.ht_cap[c];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            if (e >= cnt) break;
+            const int32_t key = kv[j][e];
+            bool seen = false;
+#pragma unroll
+            for (int f = 0; f < e; f++) seen = seen || kv[j][f] == key;
+            if (!seen && lds_slots) {             // snapshot probe
+              const unsigned long long want = pack_key(key);
+              unsigned h = hash_key(key, cap);
+              for (int probe = 0; probe < cap; probe++) {
+                const unsigned long long cur = l_slot[L.ht_off[c] + h];
+                if (cur == want) { seen = true; break; }
+                if (cur == 0ull) break;
+                h = (h + 1) & (cap - 1);
+              }
+            }
+            if (!seen) dict_insert(slots, cap, key, D.flags);
+          }
+        }
+      }
     }
   }
 }
@@ -270,9 +325,11 @@ size_t cat_lds_bytes(const CatLayout &L) {
 hipError_t launch_cat_insert(const CatCols &cols, uint64_t rows, const CatLayout &L,
                              const CatDevice &D, hipStream_t stream) {
   if (rows == 0 || L.m == 0) return hipSuccess;
-  uint64_t blocks = (rows + 255) / 256;
+  uint64_t blocks = (rows + 1023) / 1024;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cat_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, cols, rows, L, D);
+  const int lds_slots = (size_t)L.n_slots * 8 <= 48 * 1024 ? L.n_slots : 0;
+  hipLaunchKernelGGL(cat_insert_kernel, dim3((unsigned)blocks), dim3(256), (size_t)lds_slots * 8, stream,
+                     cols, rows, L, D, lds_slots);
   return hipGetLastError();
 }
 

@@ -44,6 +44,9 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
                        double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
                        hipEvent_t ev1 = nullptr);
 
+// adds the per-workgroup images partials[slot][wg] into acc[slot] in a fixed order
+hipError_t launch_gram_fold(const double *partials, int nwg, double *acc, hipStream_t stream);
+
 // ---- categorical tables -----------------------------------------------------------------------
 constexpr int MAX_PAIRS = COFACTOR_MAX_CAT * (COFACTOR_MAX_CAT + 1) / 2;
 
@@ -84,5 +87,18 @@ hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const
 // copies the count / sum / pair tables from the old strides to the new ones (code growth)
 hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
                                const CatDevice &Dnew, hipStream_t stream);
+
+// ---- fused dense + categorical kernel for low-cardinality keys (fused.hip) ----------------------
+constexpr int FUSED_MAX_SBLOCKS = 6;    // 32x32 fp32 accumulators one wave may hold (96 registers)
+// True when the shape can run on fused_kernel: triple kind, n >= 1, m >= 1, every column has at
+// most 16 keys, the S accumulators fit the register budget and the LDS image fits lds_limit.
+bool fused_applicable(const CatLayout &L, const int32_t *nkeys, size_t lds_limit, size_t *lds_bytes);
+// workgroups the fused kernel is launched with, and the bytes of per-workgroup pair slabs it needs
+int fused_grid(const CatLayout &L, int cus, int partials_cap_wgs, uint64_t rows);
+size_t fused_slab_bytes(const CatLayout &L, int grid);
+hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
+                        const CatDevice &D, int grid, double *partials, unsigned *pair_slabs,
+                        double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                        hipEvent_t ev1 = nullptr);
 
 }  // namespace cofactor

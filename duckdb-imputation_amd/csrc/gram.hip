@@ -221,6 +221,11 @@ hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partia
 
 }  // namespace
 
+hipError_t launch_gram_fold(const double *partials, int nwg, double *acc, hipStream_t stream) {
+  hipLaunchKernelGGL(gram_fold_kernel, dim3(GRAM_ACC_LEN), dim3(256), 0, stream, partials, nwg, acc);
+  return hipGetLastError();
+}
+
 hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
                        double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (rows == 0 || n == 0) return hipSuccess;
@@ -245,8 +250,7 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
   }
   if (e != hipSuccess) return e;
   if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
-  hipLaunchKernelGGL(gram_fold_kernel, dim3(GRAM_ACC_LEN), dim3(256), 0, stream, partials, grid, acc);
-  return hipGetLastError();
+  return launch_gram_fold(partials, grid, acc, stream);
 }
 
 }  // namespace cofactor

@@ -71,13 +71,15 @@ cofactor_status cofactor_ctx_synchronize(cofactor_ctx *ctx);
 /* The hipStream_t all of this context's kernels are launched on (for event timing). */
 void *cofactor_ctx_stream(cofactor_ctx *ctx);
 
-/* Optional timing of the two streaming kernels with HIP events recorded on the context stream
- * right around each launch (bench.py's roofline figures).  read synchronises the stream, returns
- * the summed kernel milliseconds and launch counts since the previous read, and clears them. */
+/* Optional timing of the streaming kernels (gram_kernel, cat_accumulate_kernel, fused_kernel) with
+ * HIP events recorded on the context stream right around each launch (bench.py's roofline
+ * figures).  read synchronises the stream, returns the summed kernel milliseconds and launch
+ * counts since the previous read, and clears them.  Any output pointer may be NULL. */
 cofactor_status cofactor_ctx_profile_enable(cofactor_ctx *ctx, int on);
 cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms,
                                           uint64_t *gram_launches, double *cat_ms,
-                                          uint64_t *cat_launches);
+                                          uint64_t *cat_launches, double *fused_ms,
+                                          uint64_t *fused_launches);
 
 /* ---- aggregate state ------------------------------------------------------------------------
  * Replaces Triple::SumState + StateFunction::Initialize/Destroy
