@@ -236,21 +236,25 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
     ls_lo = ls_hi = f32x2{0.f, 0.f};
   };
   auto flush_s = [&]() {
+    // D register g of this lane is table cell (A-row i, B-column r32) with
+    // i = (g&3) + 8*(g>>2) + 4*h32: key column 2p + (g>>3), code i & 15; B-column r32 is piece
+    // column 32*bb + r32, i.e. numeric column s_k[bb].  Address = uniform part + one lane term.
 #pragma unroll
-    for (int p = 0; p < MP; p++)
+    for (int bb = 0; bb < NBB; bb++) {
+      const int lane_term = 4 * h32 * n + s_k[bb];
 #pragma unroll
-      for (int bb = 0; bb < NBB; bb++)
+      for (int p = 0; p < MP; p++)
 #pragma unroll
         for (int g = 0; g < 16; g++) {
-          // D register g of this lane: A-row i = (g&3) + 8*(g>>2) + 4*h32 -> column 2p + (g>>3),
-          // code (i & 15); B-column r32 -> piece column 32*bb + r32 -> numeric column s_k[bb]
           const int c = 2 * p + (g >> 3);
-          const int code = (g & 3) + 8 * ((g >> 2) & 1) + 4 * h32;
           const float v = sacc[p][bb][g];
-          if (c < m && s_ok[bb] && v != 0.f)
-            unsafeAtomicAdd(&l_s[L.s_off[c] + code * n + s_k[bb]], (double)v);
+          if (c < m && s_ok[bb] && v != 0.f) {
+            const int uni = __builtin_amdgcn_readfirstlane(L.s_off[c] + ((g & 3) + 8 * ((g >> 2) & 1)) * n);
+            unsafeAtomicAdd(&l_s[uni + lane_term], (double)v);
+          }
           sacc[p][bb][g] = 0.f;
         }
+    }
   };
   // packed 16-bit pair cells -> this workgroup's private u32 slab in HBM (first time: store)
   unsigned *slab = pair_slabs + (uint64_t)blockIdx.x * (uint64_t)(2 * n_pw);
