@@ -386,16 +386,23 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
       }
     }
     if (!a->kind) {
+      // visit codes in ascending key order so that every map insertion is an append
+      std::vector<std::vector<int>> order(a->m);
+      for (int c = 0; c < a->m; c++) {
+        for (int k = 0; k < L.kc[c]; k++)
+          if (live[c][k]) order[c].push_back(k);
+        std::sort(order[c].begin(), order[c].end(), [&](int x, int y) { return key_of[c][x] < key_of[c][y]; });
+      }
       int q = 0;
       for (int c1 = 0; c1 < a->m; c1++)
-        for (int c2 = c1; c2 < a->m; c2++, q++)
-          for (int k1 = 0; k1 < L.kc[c1]; k1++) {
-            if (!live[c1][k1]) continue;
-            for (int k2 = 0; k2 < L.kc[c2]; k2++) {
+        for (int c2 = c1; c2 < a->m; c2++, q++) {
+          auto &tab = out.pair[q];
+          for (int k1 : order[c1])
+            for (int k2 : order[c2]) {
               const unsigned long long v = p[L.p_off[q] + (size_t)k1 * L.kc[c2] + k2];
-              if (v) out.pair[q][{key_of[c1][k1], key_of[c2][k2]}] = (double)v;
+              if (v) tab.emplace_hint(tab.end(), std::make_pair(key_of[c1][k1], key_of[c2][k2]), (double)v);
             }
-          }
+        }
     }
   }
   if (dense_only) {

@@ -80,8 +80,9 @@ __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
 
 // bf16 piece `q` (0 = hi, 1 = mid, 2 = lo; x = hi + mid + lo exactly) of 8 floats, packed.
 // m1 / m2 are 0xFFFF0000 when q >= 1 / q >= 2, else 0.
-__device__ __forceinline__ bf16x8 pieces8(const f32x4 &xa, const f32x4 &xb, unsigned m1, unsigned m2,
-                                          bool first) {
+// Non-finite values come out as 0 here: 0 x inf would poison every key's cell in the one-hot
+// product, so rows holding inf / nan are added to their own key's cells in phase 2 instead.
+__device__ __forceinline__ bf16x8 pieces8(const f32x4 &xa, const f32x4 &xb, unsigned m1, unsigned m2) {
   unsigned b[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) {
@@ -89,15 +90,15 @@ __device__ __forceinline__ bf16x8 pieces8(const f32x4 &xa, const f32x4 &xb, unsi
     const unsigned u = __float_as_uint(x);
     const float t1 = x - __uint_as_float(u & m1);
     const float t2 = t1 - __uint_as_float(__float_as_uint(t1) & m2);
-    const bool fin = (u & 0x7F800000u) != 0x7F800000u;   // inf / nan ride in the hi piece alone
-    b[e] = (fin || first) ? __float_as_uint(t2) >> 16 : 0u;
+    const bool fin = (u & 0x7F800000u) != 0x7F800000u;
+    b[e] = fin ? __float_as_uint(t2) >> 16 : 0u;
   }
   uint4 o = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
   return __builtin_bit_cast(bf16x8, o);
 }
 
 struct FusedCarve {   // byte offsets into the dynamic LDS block
-  int xt, codes, s, slot, dcode, cnt, pairs, total;
+  int xt, codes, s, slot, dcode, cnt, pairs, nf, total;
 };
 
 template <int NB, int NBB, int MP>
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
   int32_t *l_dcode = reinterpret_cast<int32_t *>(lds + cv.dcode);
   unsigned *l_cnt = reinterpret_cast<unsigned *>(lds + cv.cnt);
   unsigned *l_p = reinterpret_cast<unsigned *>(lds + cv.pairs);   // two 16-bit cells per dword
+  int *l_nf = reinterpret_cast<int *>(lds + cv.nf);               // [tile parity]: tile holds inf / nan
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
   for (int i = tid; i < L.n_cnt; i += GRAM_THREADS) l_cnt[i] = 0u;
   for (int i = tid; i < L.n_s; i += GRAM_THREADS) l_s[i] = 0.0;
   for (int i = tid; i < n_pw; i += GRAM_THREADS) l_p[i] = 0u;
+  if (tid < 2) l_nf[tid] = 0;
 
   // ---- lane roles ----------------------------------------------------------------------------
   int colA = NBC, colB = NBC;                              // Gram operand columns (gram.hip)
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
   const int r32 = lane & 31, h32 = lane >> 5;              // 32x32x16 operand roles
   const unsigned ii = (unsigned)(r32 & 15) * 0x00010001u;  // this lane's code value, twice
   int s_k[NBB];                                            // numeric column of this lane's piece column
-  bool s_ok[NBB], s_first[NBB];
+  bool s_ok[NBB];
   unsigned s_m1[NBB], s_m2[NBB];
 #pragma unroll
   for (int bb = 0; bb < NBB; bb++) {
@@ -154,7 +157,6 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
     s_ok[bb] = pc < 3 * n;
     const int q = s_ok[bb] ? pc / n : 0;
     s_k[bb] = s_ok[bb] ? pc % n : NBC;                     // column NBC of xt is all zero
-    s_first[bb] = q == 0;
     s_m1[bb] = q >= 1 ? 0xFFFF0000u : 0u;
     s_m2[bb] = q >= 2 ? 0xFFFF0000u : 0u;
   }
@@ -193,13 +195,17 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
       }
     }
   };
-  auto park = [&](uint64_t t) {
+  auto park = [&](uint64_t t, int parity) {
     const uint64_t r0 = t * TR + 4 * (uint64_t)lane;
 #pragma unroll
     for (int i = 0; i < LDX; i++) {
       const int vc = wave + 4 * i;
       if (vc < n) {
         *reinterpret_cast<uint4 *>(&xt[vc * XCS + 4 * lane]) = pre[i];
+        const unsigned e0 = pre[i].x & 0x7F800000u, e1 = pre[i].y & 0x7F800000u,
+                       e2 = pre[i].z & 0x7F800000u, e3 = pre[i].w & 0x7F800000u;
+        if (e0 == 0x7F800000u || e1 == 0x7F800000u || e2 == 0x7F800000u || e3 == 0x7F800000u)
+          l_nf[parity] = 1;
       } else if (vc < n + m) {
         const int c = vc - n;
         const unsigned long long *slots = l_slot + L.ht_off[c];
@@ -280,10 +286,13 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
   __syncthreads();                                          // LDS setup visible
   uint64_t t = blockIdx.x;
   if (t < ntiles) fetch(t);
-  int since_g = 0, since_s = 0, since_p = 0;
+  int since_g = 0, since_s = 0, since_p = 0, parity = 0;
   while (t < ntiles) {
-    park(t);
+    park(t, parity);
     __syncthreads();
+    const bool nonfinite = l_nf[parity] != 0;              // rare: some x of this tile is inf / nan
+    parity ^= 1;
+    if (tid == 0) l_nf[parity] = 0;                        // the flag the NEXT park may raise
     const uint64_t tn = t + gridDim.x;
     if (tn < ntiles) fetch(tn);                             // next tile flies under phases 2 and 3
 
@@ -319,6 +328,14 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
               if (c2 != c1) atomicAdd(&l_p[128 * q + row8[c1] + half[c2]], inc[c2]);
               q++;
             }
+        if (nonfinite)                                      // pieces8 fed 0 for these values
+          for (int k = 0; k < n; k++) {
+            const float x = xt[k * XCS + tid];
+            if ((__float_as_uint(x) & 0x7F800000u) == 0x7F800000u)
+#pragma unroll
+              for (int c = 0; c < MC; c++)
+                if (c < m) unsafeAtomicAdd(&l_s[L.s_off[c] + (int)cd[c] * n + k], (double)x);
+          }
       }
     }
 
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
 #pragma unroll
       for (int bb = 0; bb < NBB; bb++) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(&xt[s_k[bb] * XCS + row8]);
-        bop[bb] = pieces8(src[0], src[1], s_m1[bb], s_m2[bb], s_first[bb]);
+        bop[bb] = pieces8(src[0], src[1], s_m1[bb], s_m2[bb]);
       }
 #pragma unroll
       for (int p = 0; p < MP; p++) {
@@ -417,6 +434,7 @@ FusedCarve make_carve(const CatLayout &L, int nb) {
   c.dcode = take((size_t)L.n_slots * 4, 4);
   c.cnt = take((size_t)L.n_cnt * 4, 4);
   c.pairs = take((size_t)((L.n_p + 1) / 2) * 4, 4);
+  c.nf = take(8, 4);
   c.total = (int)((o + 15) / 16 * 16);
   return c;
 }
