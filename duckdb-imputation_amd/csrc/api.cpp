@@ -227,7 +227,8 @@ cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t r
   return COFACTOR_OK;
 }
 
-cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows) {
+cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows,
+                               bool timed = true) {
   hipStream_t st = a->ctx->stream;
   const size_t lds = cat_lds_bytes(a->L);
   const bool lds_tables = lds <= a->ctx->lds_budget;
@@ -239,7 +240,7 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
   }
 #endif
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (a->ctx->profiling) {
+  if (a->ctx->profiling && timed) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     a->ctx->cat_ev.emplace_back(e0, e1);
@@ -266,14 +267,21 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
     HIP_TRY(hipStreamSynchronize(st));
   }
 #endif
+  if (fused) {                                    // whole tiles of aligned columns only
+    for (int k = 0; k < a->n; k++) fused = fused && (reinterpret_cast<uintptr_t>(num.p[k]) & 15) == 0;
+    for (int c = 0; c < a->m; c++) fused = fused && (reinterpret_cast<uintptr_t>(cat.p[c]) & 15) == 0;
+    fused = fused && rows >= FUSED_TILE_ROWS;
+  }
+  uint64_t done = 0;
   if (fused) {                                    // one pass: dense + categorical
+    const uint64_t main_rows = rows - rows % FUSED_TILE_ROWS;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profiling) {
       HIP_TRY(hipEventCreate(&e0));
       HIP_TRY(hipEventCreate(&e1));
       ctx->fused_ev.emplace_back(e0, e1);
     }
-    const int grid = fused_grid(a->L, ctx->cus, ctx->gram_grid, rows);
+    const int grid = fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows);
     const size_t slab = fused_slab_bytes(a->L, grid);
     if (slab > ctx->pair_slab_bytes) {            // grow the per-workgroup pair slabs
       HIP_TRY(hipStreamSynchronize(st));
@@ -283,20 +291,27 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       HIP_TRY(hipMalloc((void **)&ctx->pair_slabs, slab));
       ctx->pair_slab_bytes = slab;
     }
-    HIP_TRY(launch_fused(num, cat, rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, a->d_acc, st,
+    HIP_TRY(launch_fused(num, cat, main_rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, a->d_acc, st,
                          e0, e1));
-  } else {
+    done = main_rows;
+  }
+  if (done < rows) {                              // two-kernel path (all rows, or the < 256-row tail)
+    NumCols tnum = num;
+    CatCols tcat = cat;
+    for (int k = 0; k < a->n; k++) tnum.p[k] = num.p[k] + done;
+    for (int c = 0; c < a->m; c++) tcat.p[c] = cat.p[c] + done;
+    const uint64_t trows = rows - done;
     if (a->n > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (ctx->profiling) {
+      if (ctx->profiling && !fused) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         ctx->gram_ev.emplace_back(e0, e1);
       }
-      HIP_TRY(launch_gram(num, a->n, rows, ctx->gram_grid, ctx->partials, a->d_acc, st, e0, e1));
+      HIP_TRY(launch_gram(tnum, a->n, trows, ctx->gram_grid, ctx->partials, a->d_acc, st, e0, e1));
     }
     if (a->m > 0) {
-      cofactor_status s = cat_accumulate(a, num, cat, rows);
+      cofactor_status s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/!fused);
       if (s != COFACTOR_OK) return s;
     }
   }

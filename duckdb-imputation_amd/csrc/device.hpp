@@ -89,9 +89,12 @@ hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, con
                                const CatDevice &Dnew, hipStream_t stream);
 
 // ---- fused dense + categorical kernel for low-cardinality keys (fused.hip) ----------------------
-constexpr int FUSED_MAX_SBLOCKS = 6;    // 32x32 fp32 accumulators one wave may hold (96 registers)
+constexpr int FUSED_MAX_SBLOCKS = 5;    // 32x32 fp32 accumulators one wave may hold (80 of its 168 registers)
 // True when the shape can run on fused_kernel: triple kind, n >= 1, m >= 1, every column has at
 // most 16 keys, the S accumulators fit the register budget and the LDS image fits lds_limit.
+// The kernel takes whole 256-row tiles of 16-byte aligned columns (FUSED_TILE_ROWS); the caller
+// sends the remaining rows (< 256) through the two-kernel path.
+constexpr int FUSED_TILE_ROWS = GRAM_TILE_ROWS;
 bool fused_applicable(const CatLayout &L, const int32_t *nkeys, size_t lds_limit, size_t *lds_bytes);
 // workgroups the fused kernel is launched with, and the bytes of per-workgroup pair slabs it needs
 int fused_grid(const CatLayout &L, int cus, int partials_cap_wgs, uint64_t rows);

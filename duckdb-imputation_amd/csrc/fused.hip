@@ -6,16 +6,17 @@
 //
 // Reference loops replaced: duckdb_extension/src/triple/sum/sum_no_lift.cpp:119-214.
 //
-// Per 256-row tile (512 threads = 8 waves, two workgroups per CU so that one's LDS-atomic phase
-// overlaps the other's MFMA phase; grid-stride, next tile's loads in flight):
-//   phase 1  every wave parks whole columns: float columns go to the Gram tile xt[col][row];
-//            key columns are looked up in the LDS copy of the column's dictionary and their
-//            codes go to codes[col][row] (u16).
-//   phase 2  two threads per row: m count increments (ds_add_u32) and m(m+1)/2 pair-count
-//            increments into LDS tables whose cells are 16 bit wide, two per dword (half the
-//            LDS); every 240 tiles, before a cell can wrap, the workgroup adds its pair table
-//            into its private slab in HBM (plain read-modify-write, no contention).
-//   phase 3  each wave, for its 32 rows: the dense Gram with one v_mfma_f32_4x4x1_16b_f32 per
+// Workgroup = 512 threads = two teams of 4 waves working on 256-row tiles, double-buffered in LDS:
+// while the MFMA team (waves 4-7) eats tile k, the loader team (waves 0-3) counts tile k and
+// prepares tile k+1 in the other buffer, so the LDS-atomic work and the matrix work of one CU
+// overlap by construction (one barrier per tile).
+//   loaders  park whole columns: float columns go to the Gram tile xt[col][row]; key columns are
+//            looked up in the LDS copy of the column's dictionary and their codes go to
+//            codes[col][row] (u16).  Then, one thread per row: m count increments (ds_add_u32)
+//            and m(m-1)/2 pair-count increments into LDS tables whose cells are 16 bit wide, two
+//            per dword (half the LDS); every 240 tiles, before a cell can wrap, the team adds the
+//            pair table into the workgroup's private slab in HBM (no contention).
+//   MFMA team each wave, for its 64 rows: the dense Gram with one v_mfma_f32_4x4x1_16b_f32 per
 //            row (as gram.hip), and the per-key sums as ONE-HOT x PIECES products on
 //            v_mfma_f32_32x32x16_bf16: A = one-hot(code) of two key columns (32 rows of A =
 //            2 x 16 codes), B = x split exactly into three bf16 pieces (x = hi + mid + lo, 3n <= 32
@@ -42,24 +43,41 @@ constexpr int XCS = GRAM_COL_STRIDE;    // float stride of an xt column
 constexpr int PTS = TR + 8;             // u16 stride of a codes column (528 B, 16-B aligned)
 constexpr int S_FLUSH_TILES = 8;
 constexpr int G_FLUSH_TILES = 4;
+constexpr int LOAD_RING = 2;            // tiles whose loads the loader team keeps in flight
 constexpr int P_FLUSH_TILES = 240;      // 240 * 256 rows < 65536: a 16-bit pair cell cannot wrap
 
 __device__ __forceinline__ unsigned fhash(int32_t key, int cap) {
   return ((unsigned)key * 0x9E3779B1u) >> (32 - (31 - __builtin_clz(cap)));
 }
 
-// code of `key` in the LDS copy of a dictionary, 0xFFFF if absent
-__device__ __forceinline__ unsigned lds_lookup(const unsigned long long *slots, const int32_t *codes,
-                                               int cap, int32_t key) {
-  const unsigned long long want = (1ull << 32) | (unsigned long long)(unsigned)key;
-  unsigned h = fhash(key, cap);
+// codes of 4 keys in the LDS copy of a dictionary (0xFFFF if absent), packed as 4 x u16.  The four
+// probe chains advance together, so their LDS round trips overlap.  One copy in the code object
+// (called 2.5 times per loader wave and tile): the loader loop has to stay small.
+__device__ __noinline__ uint2 lds_lookup4(const unsigned long long *slots, const int32_t *codes, int cap,
+                                          uint4 keys) {
+  const unsigned key[4] = {keys.x, keys.y, keys.z, keys.w};
+  unsigned h[4], cd[4];
+  bool open[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) { h[e] = fhash((int32_t)key[e], cap); open[e] = true; cd[e] = 0xFFFFu; }
   for (int probe = 0; probe < cap; probe++) {
-    const unsigned long long cur = slots[h];
-    if (cur == want) return (unsigned)codes[h] & 0xFFFFu;
-    if (cur == 0ull) break;
-    h = (h + 1) & (cap - 1);
+    unsigned long long cur[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) cur[e] = slots[h[e]];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const unsigned long long want = (1ull << 32) | (unsigned long long)key[e];
+      if (open[e]) {
+        if (cur[e] == want) { cd[e] = (unsigned)codes[h[e]] & 0xFFFFu; open[e] = false; }
+        else if (cur[e] == 0ull) open[e] = false;
+        else h[e] = (h[e] + 1) & (cap - 1);
+      }
+      any = any || open[e];
+    }
+    if (!any) break;
   }
-  return 0xFFFFu;
+  return make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
 }
 
 // 8 u16 codes (uint4) -> 8 bf16 one-hot values for code value i: 1.0 (0x3F80) where equal
@@ -78,64 +96,60 @@ __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
   return __builtin_bit_cast(bf16x8, o);
 }
 
-// bf16 piece `q` (0 = hi, 1 = mid, 2 = lo; x = hi + mid + lo exactly) of 8 floats, packed.
-// m1 / m2 are 0xFFFF0000 when q >= 1 / q >= 2, else 0.
-// Non-finite values come out as 0 here: 0 x inf would poison every key's cell in the one-hot
-// product, so rows holding inf / nan are added to their own key's cells in phase 2 instead.
-__device__ __forceinline__ bf16x8 pieces8(const f32x4 &xa, const f32x4 &xb, unsigned m1, unsigned m2) {
-  unsigned b[8];
-#pragma unroll
-  for (int e = 0; e < 8; e++) {
-    const float x = e < 4 ? xa[e] : xb[e - 4];
-    const unsigned u = __float_as_uint(x);
-    const float t1 = x - __uint_as_float(u & m1);
-    const float t2 = t1 - __uint_as_float(__float_as_uint(t1) & m2);
-    const bool fin = (u & 0x7F800000u) != 0x7F800000u;
-    b[e] = fin ? __float_as_uint(t2) >> 16 : 0u;
-  }
-  uint4 o = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
-  return __builtin_bit_cast(bf16x8, o);
-}
+constexpr int FUSED_THREADS = 768;      // waves 0-3 loaders, 4-7 counters, 8-11 MFMA team
+constexpr int TEAM = 256;
 
 struct FusedCarve {   // byte offsets into the dynamic LDS block
-  int xt, codes, s, slot, dcode, cnt, pairs, nf, total;
+  int xt, xt_stride, pt, pt_stride, codes, codes_stride, s, slot, dcode, cnt, pairs, nf, gsum, total;
 };
 
-template <int NB, int NBB, int MP>
-__global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, CatCols cat, uint64_t rows,
-                                                                CatLayout L, CatDevice D, FusedCarve cv,
-                                                                double *__restrict__ partials,
-                                                                unsigned *__restrict__ pair_slabs) {
+template <int NB, int NBB, int M>
+__global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCols cat, uint64_t rows,
+                                                              CatLayout L, CatDevice D, FusedCarve cv,
+                                                              double *__restrict__ partials,
+                                                              unsigned *__restrict__ pair_slabs) {
   constexpr int NPAIR = NB * (NB + 1) / 2;
   constexpr int NBC = 4 * NB;
-  constexpr int MC = 2 * MP;                               // unroll bound for key columns
-  constexpr int LDX = NB + (MP + 1) / 2;                   // 16-B loads per thread per tile
+  constexpr int MP = (M + 1) / 2;                          // key columns are processed in pairs by the MFMA team
+  constexpr int MC = M;                                    // number of key columns, compile-time
+  constexpr int LDX = NB + (M + 3) / 4;                    // 16-B loads per loader thread per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  float *xt = reinterpret_cast<float *>(lds + cv.xt);
-  unsigned short *codes = reinterpret_cast<unsigned short *>(lds + cv.codes);
   double *l_s = reinterpret_cast<double *>(lds + cv.s);
   unsigned long long *l_slot = reinterpret_cast<unsigned long long *>(lds + cv.slot);
   int32_t *l_dcode = reinterpret_cast<int32_t *>(lds + cv.dcode);
   unsigned *l_cnt = reinterpret_cast<unsigned *>(lds + cv.cnt);
   unsigned *l_p = reinterpret_cast<unsigned *>(lds + cv.pairs);   // two 16-bit cells per dword
-  int *l_nf = reinterpret_cast<int *>(lds + cv.nf);               // [tile parity]: tile holds inf / nan
+  unsigned *l_nf = reinterpret_cast<unsigned *>(lds + cv.nf);     // [buffer]: stamp of a tile holding inf / nan
+  auto xt_of = [&](int b) { return reinterpret_cast<float *>(lds + cv.xt + b * cv.xt_stride); };
+  auto pt_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.pt + b * cv.pt_stride); };
+  auto codes_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.codes + b * cv.codes_stride); };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = L.n, m = L.m;
+  const int team = wave >> 2;                              // 0 loaders, 1 counters, 2 MFMA
+  const int tw = wave & 3;                                 // wave index inside its team
+  const int tt = tid & (TEAM - 1);                         // thread index inside its team
+  const int n = L.n;
+  constexpr int m = M;
   const int n_pw = (L.n_p + 1) / 2;                        // dwords of the packed pair table
 
   // ---- one-time LDS setup ------------------------------------------------------------------
-  for (int i = tid; i < (NBC + 1) * XCS; i += GRAM_THREADS) xt[i] = 0.f;
-  for (int i = tid; i < (m + 1) * PTS; i += GRAM_THREADS) codes[i] = 0xFFFF;   // column m stays 0xFFFF
-  for (int i = tid; i < L.n_slots; i += GRAM_THREADS) { l_slot[i] = D.ht_slot[i]; l_dcode[i] = D.ht_code[i]; }
-  for (int i = tid; i < L.n_cnt; i += GRAM_THREADS) l_cnt[i] = 0u;
-  for (int i = tid; i < L.n_s; i += GRAM_THREADS) l_s[i] = 0.0;
-  for (int i = tid; i < n_pw; i += GRAM_THREADS) l_p[i] = 0u;
-  if (tid < 2) l_nf[tid] = 0;
+  for (int b = 0; b < 2; b++) {
+    float *x = xt_of(b);
+    unsigned short *cd = codes_of(b);
+    for (int i = tid; i < (NBC + 1) * XCS; i += FUSED_THREADS) x[i] = 0.f;
+    unsigned short *pz = pt_of(b);
+    for (int i = tid; i < 32 * NBB * PTS; i += FUSED_THREADS) pz[i] = 0;   // piece columns >= 3n stay 0
+    for (int i = tid; i < (m + 1) * PTS; i += FUSED_THREADS) cd[i] = 0xFFFF;   // column m stays 0xFFFF
+  }
+  for (int i = tid; i < L.n_slots; i += FUSED_THREADS) { l_slot[i] = D.ht_slot[i]; l_dcode[i] = D.ht_code[i]; }
+  for (int i = tid; i < L.n_cnt; i += FUSED_THREADS) l_cnt[i] = 0u;
+  for (int i = tid; i < L.n_s; i += FUSED_THREADS) l_s[i] = 0.0;
+  for (int i = tid; i < n_pw; i += FUSED_THREADS) l_p[i] = 0u;
+  if (tid < 2) l_nf[tid] = 0u;
 
-  // ---- lane roles ----------------------------------------------------------------------------
+  // ---- lane roles of the MFMA team -------------------------------------------------------------
   int colA = NBC, colB = NBC;                              // Gram operand columns (gram.hip)
   {
     const int b = lane >> 2, t = lane & 3;
@@ -150,15 +164,11 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
   const unsigned ii = (unsigned)(r32 & 15) * 0x00010001u;  // this lane's code value, twice
   int s_k[NBB];                                            // numeric column of this lane's piece column
   bool s_ok[NBB];
-  unsigned s_m1[NBB], s_m2[NBB];
 #pragma unroll
   for (int bb = 0; bb < NBB; bb++) {
     const int pc = 32 * bb + r32;                          // piece column = piece * n + numeric column
     s_ok[bb] = pc < 3 * n;
-    const int q = s_ok[bb] ? pc / n : 0;
-    s_k[bb] = s_ok[bb] ? pc % n : NBC;                     // column NBC of xt is all zero
-    s_m1[bb] = q >= 1 ? 0xFFFF0000u : 0u;
-    s_m2[bb] = q >= 2 ? 0xFFFF0000u : 0u;
+    s_k[bb] = s_ok[bb] ? pc % n : 0;
   }
 
 #ifdef COFACTOR_DEV_ABLATE   // timing experiments only (results are wrong when a bit is set)
@@ -166,64 +176,129 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
 #else
   constexpr int ablate = 0;
 #endif
-  const uint64_t ntiles = (rows + TR - 1) / TR;
-  uint4 pre[LDX];
-  auto fetch = [&](uint64_t t) {
+  const uint64_t ntiles = rows / TR;                        // whole tiles only
+
+  // ---- loader team: tile fetch (global -> registers) and park (registers -> LDS) ---------------
+  // (the launcher only hands this kernel whole tiles of 16-byte aligned columns)
+  auto fetch = [&](uint4 (&pre)[LDX], uint64_t t) {
     const uint64_t r0 = t * TR + 4 * (uint64_t)lane;
-    const bool full = t * TR + TR <= rows;
 #pragma unroll
     for (int i = 0; i < LDX; i++) {
-      const int vc = wave + 4 * i;                         // wave-uniform virtual column
+      const int vc = tw + 4 * i;                           // wave-uniform virtual column
       if (vc < n + m) {
         const unsigned *src = vc < n ? reinterpret_cast<const unsigned *>(num.p[vc])
                                      : reinterpret_cast<const unsigned *>(cat.p[vc - n]);
-        if (full) {
-          if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + r0));
-            pre[i] = __builtin_bit_cast(uint4, v);
-          } else {
-            pre[i] = make_uint4(src[r0], src[r0 + 1], src[r0 + 2], src[r0 + 3]);
-          }
-        } else {
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);            // rows past the end: x = 0 (neutral)
-          if (r0 < rows) v.x = src[r0];
-          if (r0 + 1 < rows) v.y = src[r0 + 1];
-          if (r0 + 2 < rows) v.z = src[r0 + 2];
-          if (r0 + 3 < rows) v.w = src[r0 + 3];
-          pre[i] = v;
-        }
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + r0));
+        pre[i] = __builtin_bit_cast(uint4, v);
       }
     }
   };
-  auto park = [&](uint64_t t, int parity) {
-    const uint64_t r0 = t * TR + 4 * (uint64_t)lane;
+  auto park = [&](const uint4 (&pre)[LDX], int b, unsigned stamp) {
+    float *xt = xt_of(b);
+    unsigned short *pt = pt_of(b);
+    unsigned short *codes = codes_of(b);
 #pragma unroll
     for (int i = 0; i < LDX; i++) {
-      const int vc = wave + 4 * i;
+      const int vc = tw + 4 * i;
       if (vc < n) {
         *reinterpret_cast<uint4 *>(&xt[vc * XCS + 4 * lane]) = pre[i];
-        const unsigned e0 = pre[i].x & 0x7F800000u, e1 = pre[i].y & 0x7F800000u,
-                       e2 = pre[i].z & 0x7F800000u, e3 = pre[i].w & 0x7F800000u;
-        if (e0 == 0x7F800000u || e1 == 0x7F800000u || e2 == 0x7F800000u || e3 == 0x7F800000u)
-          l_nf[parity] = 1;
+        // x = hi + mid + lo, each a bf16 (exact); inf / nan become 0 here and are added to their
+        // own key's cells by the counters (0 x inf would poison every key's cell)
+        const unsigned u[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+        unsigned hi[4], mi[4], lo[4];
+        bool nonfinite = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float x = __uint_as_float(u[e]);
+          const unsigned uh = u[e] & 0xFFFF0000u;
+          const float r1 = x - __uint_as_float(uh);
+          const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+          const float r2 = r1 - __uint_as_float(um);
+          const bool fin = (u[e] & 0x7F800000u) != 0x7F800000u;
+          nonfinite = nonfinite || !fin;
+          hi[e] = fin ? uh >> 16 : 0u;
+          mi[e] = fin ? um >> 16 : 0u;
+          lo[e] = fin ? __float_as_uint(r2) >> 16 : 0u;
+        }
+        *reinterpret_cast<uint2 *>(&pt[vc * PTS + 4 * lane]) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+        *reinterpret_cast<uint2 *>(&pt[(n + vc) * PTS + 4 * lane]) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
+        *reinterpret_cast<uint2 *>(&pt[(2 * n + vc) * PTS + 4 * lane]) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        if (nonfinite) l_nf[b] = stamp;                     // this tile holds inf / nan
       } else if (vc < n + m) {
         const int c = vc - n;
         const unsigned long long *slots = l_slot + L.ht_off[c];
         const int32_t *dc = l_dcode + L.ht_off[c];
         const int cap = L.ht_cap[c];
-        const unsigned k[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
-        unsigned cd[4];
+        uint2 packed;
+        if (ablate & 8) packed = make_uint2((pre[i].x & 15u) | ((pre[i].y & 15u) << 16), (pre[i].z & 15u) | ((pre[i].w & 15u) << 16));
+        else packed = lds_lookup4(slots, dc, cap, pre[i]);
+        *reinterpret_cast<uint2 *>(&codes[c * PTS + 4 * lane]) = packed;
+      }
+    }
+  };
+  // packed 16-bit pair cells -> this workgroup's private u32 slab in HBM (first time: store).
+  // Loader team only; atomicExch makes read-and-clear safe against increments that run ahead.
+  unsigned *slab = pair_slabs + (uint64_t)blockIdx.x * (uint64_t)(2 * n_pw);
+  bool slab_fresh = true;
+  auto flush_pairs = [&]() {
+    for (int w = tt; w < n_pw; w += TEAM) {
+      const unsigned v = atomicExch(&l_p[w], 0u);
+      uint2 *dst = reinterpret_cast<uint2 *>(slab + 2 * w);
+      uint2 cur = slab_fresh ? make_uint2(0u, 0u) : *dst;
+      cur.x += v & 0xFFFFu;
+      cur.y += v >> 16;
+      *dst = cur;
+    }
+    slab_fresh = false;
+  };
+  // counts and pair counts of tile t (buffer b), one loader thread per row
+  auto count_rows = [&](int b, unsigned stamp) {
+    if (ablate & 1) return;
+    const unsigned short *codes = codes_of(b);
+    unsigned cd[MC];
+    bool known = true;
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-          cd[e] = (r0 + e < rows) ? ((ablate & 8) ? (k[e] & 15u) : lds_lookup(slots, dc, cap, (int32_t)k[e])) : 0xFFFFu;
-        *reinterpret_cast<uint2 *>(&codes[c * PTS + 4 * lane]) = make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
+    for (int c = 0; c < MC; c++)
+      if (c < m) { cd[c] = codes[c * PTS + tt]; known = known && cd[c] < (unsigned)L.kc[c]; }
+    if (!known) { D.flags[1] = 1; return; }                 // surfaces as an error at finalize
+    // every column has code capacity 16 here (fused_applicable), so pair table q starts at cell
+    // 256 q and cell = 256 q + 16 code1 + code2: dword 128 q + 8 code1 + (code2 >> 1), upper half
+    // when code2 is odd.  Diagonal pairs (c, c) only ever hit cells (k, k) with the column's own
+    // counts: they are filled from the count table at the end instead.
+    unsigned row8[MC], half[MC], inc[MC];
+#pragma unroll
+    for (int c = 0; c < MC; c++)
+      if (c < m) {
+        atomicAdd(&l_cnt[16 * c + cd[c]], 1u);
+        row8[c] = 8u * cd[c];
+        half[c] = cd[c] >> 1;
+        inc[c] = 1u << ((cd[c] & 1u) * 16u);
+      }
+    int q = 0;
+#pragma unroll
+    for (int c1 = 0; c1 < MC; c1++)
+#pragma unroll
+      for (int c2 = c1; c2 < MC; c2++)
+        if (c2 < m) {
+          if (c2 != c1) atomicAdd(&l_p[128 * q + row8[c1] + half[c2]], inc[c2]);
+          q++;
+        }
+    if (l_nf[b] == stamp) {                                 // rare: pieces8 fed 0 for inf / nan
+      const float *xt = xt_of(b);
+      for (int k = 0; k < n; k++) {
+        const float x = xt[k * XCS + tt];
+        if ((__float_as_uint(x) & 0x7F800000u) == 0x7F800000u)
+#pragma unroll
+          for (int c = 0; c < MC; c++)
+            if (c < m) unsafeAtomicAdd(&l_s[L.s_off[c] + (int)cd[c] * n + k], (double)x);
       }
     }
   };
 
+  // ---- MFMA team state ---------------------------------------------------------------------------
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   f32x2 ls_lo = {0.f, 0.f}, ls_hi = {0.f, 0.f};
-  double dq0 = 0, dq1 = 0, dq2 = 0, dq3 = 0, dl = 0;
+  double *gsum = reinterpret_cast<double *>(lds + cv.gsum) + tw * GRAM_ACC_LEN;   // this wave's fp64 Gram image
   f32x16 sacc[MP][NBB];
 #pragma unroll
   for (int p = 0; p < MP; p++)
@@ -232,12 +307,12 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
 #pragma unroll
       for (int g = 0; g < 16; g++) sacc[p][bb][g] = 0.f;
 
-  auto flush_gram = [&]() {
-    dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
-    dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
-    dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
-    dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
-    dl += (double)((ls_lo[0] + ls_lo[1]) + (ls_hi[0] + ls_hi[1]));
+  auto flush_gram = [&]() {                                // fp32 chains -> this wave's fp64 image in LDS
+    gsum[0 * 64 + lane] += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
+    gsum[1 * 64 + lane] += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
+    gsum[2 * 64 + lane] += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
+    gsum[3 * 64 + lane] += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
+    gsum[4 * 64 + lane] += (double)((ls_lo[0] + ls_lo[1]) + (ls_hi[0] + ls_hi[1]));
     acc0 = acc1 = acc2 = acc3 = f32x4{0, 0, 0, 0};
     ls_lo = ls_hi = f32x2{0.f, 0.f};
   };
@@ -262,152 +337,119 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void fused_kernel(NumCols num, Cat
         }
     }
   };
-  // packed 16-bit pair cells -> this workgroup's private u32 slab in HBM (first time: store)
-  unsigned *slab = pair_slabs + (uint64_t)blockIdx.x * (uint64_t)(2 * n_pw);
-  bool slab_fresh = true;
-  auto flush_pairs = [&]() {
-    __syncthreads();
-    for (int w = tid; w < n_pw; w += GRAM_THREADS) {
-      const unsigned v = l_p[w];
-      uint2 *dst = reinterpret_cast<uint2 *>(slab + 2 * w);
-      uint2 cur = slab_fresh ? make_uint2(0u, 0u) : *dst;
-      cur.x += v & 0xFFFFu;
-      cur.y += v >> 16;
-      *dst = cur;
-      l_p[w] = 0u;
-    }
-    slab_fresh = false;
-    __syncthreads();
-  };
-
-  const float *pa = xt + colA * XCS + wave * 64;
-  const float *pb = xt + colB * XCS + wave * 64;
-
-  __syncthreads();                                          // LDS setup visible
-  uint64_t t = blockIdx.x;
-  if (t < ntiles) fetch(t);
-  int since_g = 0, since_s = 0, since_p = 0, parity = 0;
-  while (t < ntiles) {
-    park(t, parity);
-    __syncthreads();
-    const bool nonfinite = l_nf[parity] != 0;              // rare: some x of this tile is inf / nan
-    parity ^= 1;
-    if (tid == 0) l_nf[parity] = 0;                        // the flag the NEXT park may raise
-    const uint64_t tn = t + gridDim.x;
-    if (tn < ntiles) fetch(tn);                             // next tile flies under phases 2 and 3
-
-    // ---- phase 2: counts and pair counts, one thread per row --------------------------------
-    if (!(ablate & 1) && t * TR + tid < rows) {
-      unsigned cd[MC];
-      bool known = true;
-#pragma unroll
-      for (int c = 0; c < MC; c++)
-        if (c < m) { cd[c] = codes[c * PTS + tid]; known = known && cd[c] < (unsigned)L.kc[c]; }
-      if (!known) {
-        D.flags[1] = 1;                                     // surfaces as an error at finalize
-      } else {
-        // every column has code capacity 16 here (fused_applicable), so pair table q starts at
-        // cell 256 q and cell = 256 q + 16 code1 + code2: dword 128 q + 8 code1 + (code2 >> 1),
-        // upper half when code2 is odd.  Diagonal pairs (c, c) only ever hit cells (k, k) with
-        // the column's own counts: they are filled from the count table at the end instead.
-        unsigned row8[MC], half[MC], inc[MC];
-#pragma unroll
-        for (int c = 0; c < MC; c++)
-          if (c < m) {
-            atomicAdd(&l_cnt[16 * c + cd[c]], 1u);
-            row8[c] = 8u * cd[c];
-            half[c] = cd[c] >> 1;
-            inc[c] = 1u << ((cd[c] & 1u) * 16u);
-          }
-        int q = 0;
-#pragma unroll
-        for (int c1 = 0; c1 < MC; c1++)
-#pragma unroll
-          for (int c2 = c1; c2 < MC; c2++)
-            if (c2 < m) {
-              if (c2 != c1) atomicAdd(&l_p[128 * q + row8[c1] + half[c2]], inc[c2]);
-              q++;
-            }
-        if (nonfinite)                                      // pieces8 fed 0 for these values
-          for (int k = 0; k < n; k++) {
-            const float x = xt[k * XCS + tid];
-            if ((__float_as_uint(x) & 0x7F800000u) == 0x7F800000u)
-#pragma unroll
-              for (int c = 0; c < MC; c++)
-                if (c < m) unsafeAtomicAdd(&l_s[L.s_off[c] + (int)cd[c] * n + k], (double)x);
-          }
-      }
-    }
-
-    // ---- phase 3a: dense Gram of this wave's 64 rows ----------------------------------------
+  // Gram and per-key sums of this wave's 64 rows of the tile in buffer b
+  auto crunch = [&](int b) {
+    const float *xt = xt_of(b);
+    const unsigned short *pt = pt_of(b);
+    const unsigned short *codes = codes_of(b);
     if (!(ablate & 4)) {
-      const f32x4 *va = reinterpret_cast<const f32x4 *>(pa);
-      const f32x4 *vb = reinterpret_cast<const f32x4 *>(pb);
+      const f32x4 *va = reinterpret_cast<const f32x4 *>(xt + colA * XCS + tw * 64);
+      const f32x4 *vb = reinterpret_cast<const f32x4 *>(xt + colB * XCS + tw * 64);
 #pragma unroll 4
       for (int it = 0; it < 16; it++) {
-        const f32x4 a = va[it], b = vb[it];
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc3, 0, 0, 0);
+        const f32x4 a = va[it], bv = vb[it];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], bv[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], bv[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], bv[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], bv[3], acc3, 0, 0, 0);
         ls_lo += __builtin_shufflevector(a, a, 0, 1);
         ls_hi += __builtin_shufflevector(a, a, 2, 3);
       }
     }
-    // ---- phase 3b: per-key sums, one-hot x pieces --------------------------------------------
     if (!(ablate & 2))
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int row8 = wave * 64 + g * 16 + 8 * h32;        // this lane's 8 table rows
-      bf16x8 bop[NBB];
-#pragma unroll
-      for (int bb = 0; bb < NBB; bb++) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(&xt[s_k[bb] * XCS + row8]);
-        bop[bb] = pieces8(src[0], src[1], s_m1[bb], s_m2[bb]);
-      }
-#pragma unroll
-      for (int p = 0; p < MP; p++) {
-        int c = 2 * p + (r32 >> 4);
-        c = c < m ? c : m;                                  // column m is all 0xFFFF: matches nothing
-        const uint4 cvv = *reinterpret_cast<const uint4 *>(&codes[c * PTS + row8]);
-        const bf16x8 aop = onehot8(cvv, ii);
+      for (int g = 0; g < 4; g++) {
+        const int row8 = tw * 64 + g * 16 + 8 * h32;        // this lane's 8 table rows
+        bf16x8 bop[NBB];
 #pragma unroll
         for (int bb = 0; bb < NBB; bb++)
-          sacc[p][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aop, bop[bb], sacc[p][bb], 0, 0, 0);
+          bop[bb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(&pt[(32 * bb + r32) * PTS + row8]));
+#pragma unroll
+        for (int p = 0; p < MP; p++) {
+          int c = 2 * p + (r32 >> 4);
+          c = c < m ? c : m;                                // column m is all 0xFFFF: matches nothing
+          const uint4 cvv = *reinterpret_cast<const uint4 *>(&codes[c * PTS + row8]);
+          const bf16x8 aop = onehot8(cvv, ii);
+#pragma unroll
+          for (int bb = 0; bb < NBB; bb++)
+            sacc[p][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aop, bop[bb], sacc[p][bb], 0, 0, 0);
+        }
+      }
+  };
+
+  // ---- the pipeline.  Three teams meet at ONE barrier per tile: while counters and the MFMA team
+  // consume tile k from buffer b, the loaders park tile k+1 into buffer b^1 (its loads were issued
+  // two tiles ahead) and issue the loads of tile k+3.  Each team runs its own loop, so none carries
+  // the others' registers; all execute the same number of barriers.
+  for (int i = tid; i < 4 * GRAM_ACC_LEN; i += FUSED_THREADS) reinterpret_cast<double *>(lds + cv.gsum)[i] = 0.0;
+  __syncthreads();                                          // LDS setup visible
+  const uint64_t G = gridDim.x;
+  if (team == 0) {
+    // register ring of RING tiles: tile j of this workgroup lives in set j % RING from the moment
+    // its loads are issued (RING tiles ahead of its use) until it is parked
+    constexpr int RING = LOAD_RING;
+    uint4 pre[RING][LDX];
+    uint64_t t = blockIdx.x;
+    unsigned k = 1;                                         // per-workgroup tile counter = nf stamp
+#pragma unroll
+    for (int r = 0; r < RING; r++)
+      if (t + r * G < ntiles) fetch(pre[r], t + r * G);
+    if (t < ntiles) park(pre[0], 0, k);
+    if (t + RING * G < ntiles) fetch(pre[0], t + RING * G);
+    __syncthreads();
+    int b = 0;
+    while (t < ntiles) {
+#pragma unroll
+      for (int r = 0; r < RING; r++) {                      // consuming tile j (j % RING == r)
+        const int nx = (r + 1) % RING;
+        if (t + G < ntiles) park(pre[nx], b ^ 1, k + 1);
+        if (t + (RING + 1) * G < ntiles) fetch(pre[nx], t + (RING + 1) * G);
+        __syncthreads();                                    // buffer b free, buffer b^1 complete
+        t += G; b ^= 1; k++;
+        if (t >= ntiles) break;
       }
     }
-    if (++since_g == G_FLUSH_TILES) { flush_gram(); since_g = 0; }
-    if (++since_s == S_FLUSH_TILES) { flush_s(); since_s = 0; }
-    if (++since_p == P_FLUSH_TILES) { flush_pairs(); since_p = 0; }   // uniform: same count in every thread
-    __syncthreads();                                        // all reads of this tile done
-    t = tn;
+  } else if (team == 1) {
+    __syncthreads();
+    int b = 0, since_p = 0;
+    unsigned k = 1;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += G) {
+      if (since_p == P_FLUSH_TILES) { flush_pairs(); since_p = 0; }
+      count_rows(b, k);
+      since_p++;
+      __syncthreads();
+      b ^= 1; k++;
+    }
+    flush_pairs();
+  } else {
+    __syncthreads();
+    int b = 0, since_g = 0, since_s = 0;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += G) {
+      crunch(b);
+      if (++since_g == G_FLUSH_TILES) { flush_gram(); since_g = 0; }
+      if (++since_s == S_FLUSH_TILES) { flush_s(); since_s = 0; }
+      __syncthreads();
+      b ^= 1;
+    }
+    flush_gram();
+    flush_s();
   }
-  flush_gram();
-  flush_s();
-  flush_pairs();
 
   // ---- end: Gram image of the workgroup, count / sum tables into the aggregate's HBM tables ---
   __syncthreads();
-  double *red = reinterpret_cast<double *>(xt);             // carve reserves >= 4 * 320 doubles here
-  double *mine = red + wave * GRAM_ACC_LEN;
-  mine[0 * 64 + lane] = dq0;
-  mine[1 * 64 + lane] = dq1;
-  mine[2 * 64 + lane] = dq2;
-  mine[3 * 64 + lane] = dq3;
-  mine[4 * 64 + lane] = dl;
-  __syncthreads();
-  for (int i = tid; i < GRAM_ACC_LEN; i += GRAM_THREADS) {
+  const double *red = reinterpret_cast<const double *>(lds + cv.gsum);
+  for (int i = tid; i < GRAM_ACC_LEN; i += FUSED_THREADS) {
     const double v = ((red[i] + red[GRAM_ACC_LEN + i]) + red[2 * GRAM_ACC_LEN + i]) + red[3 * GRAM_ACC_LEN + i];
     partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
   }
-  for (int i = tid; i < L.n_cnt; i += GRAM_THREADS)
+  for (int i = tid; i < L.n_cnt; i += FUSED_THREADS)
     if (l_cnt[i]) {
       atomicAdd(&D.cnt[i], (unsigned long long)l_cnt[i]);
       const int c = i >> 4, code = i & 15;                  // cnt_off[c] = 16 c in the fused layout
       const int qd = c * m - c * (c - 1) / 2;               // index of pair (c, c)
       atomicAdd(&D.p[L.p_off[qd] + code * 16 + code], (unsigned long long)l_cnt[i]);
     }
-  for (int i = tid; i < L.n_s; i += GRAM_THREADS)
+  for (int i = tid; i < L.n_s; i += FUSED_THREADS)
     if (l_s[i] != 0.0) unsafeAtomicAdd(&D.s[i], l_s[i]);
 }
 
@@ -423,40 +465,45 @@ __global__ __launch_bounds__(256) void fused_pairs_fold_kernel(const unsigned *_
 }
 
 FusedCarve make_carve(const CatLayout &L, int nb) {
+  const int nbb = (3 * L.n + 31) / 32;
   FusedCarve c{};
   size_t o = 0;
   auto take = [&](size_t bytes, size_t align) { o = (o + align - 1) / align * align; size_t at = o; o += bytes; return (int)at; };
-  c.xt = take((size_t)(4 * nb + 1) * XCS * sizeof(float), 16);
-  c.codes = take((size_t)(L.m + 1) * PTS * 2, 16);
-  if (o < sizeof(double) * 4 * GRAM_ACC_LEN) o = sizeof(double) * 4 * GRAM_ACC_LEN;   // wave-fold scratch overlays xt + codes
+  c.xt_stride = (int)((size_t)(4 * nb + 1) * XCS * sizeof(float));
+  c.xt = take((size_t)2 * c.xt_stride, 16);
+  c.pt_stride = (int)((size_t)32 * nbb * PTS * 2);
+  c.pt = take((size_t)2 * c.pt_stride, 16);
+  c.codes_stride = (int)((size_t)(L.m + 1) * PTS * 2);
+  c.codes = take((size_t)2 * c.codes_stride, 16);
   c.s = take((size_t)L.n_s * 8, 8);
   c.slot = take((size_t)L.n_slots * 8, 8);
   c.dcode = take((size_t)L.n_slots * 4, 4);
   c.cnt = take((size_t)L.n_cnt * 4, 4);
   c.pairs = take((size_t)((L.n_p + 1) / 2) * 4, 4);
   c.nf = take(8, 4);
+  c.gsum = take(sizeof(double) * 4 * GRAM_ACC_LEN, 8);
   c.total = (int)((o + 15) / 16 * 16);
   return c;
 }
 
-template <int NB, int NBB, int MP>
+template <int NB, int NBB, int M>
 hipError_t launch_one(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                       const CatDevice &D, const FusedCarve &cv, int grid, double *partials,
                       unsigned *slabs, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute((const void *)fused_kernel<NB, NBB, MP>,
+  hipError_t e = hipFuncSetAttribute((const void *)fused_kernel<NB, NBB, M>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, cv.total);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((fused_kernel<NB, NBB, MP>), dim3(grid), dim3(GRAM_THREADS), cv.total, stream, num,
+  hipLaunchKernelGGL((fused_kernel<NB, NBB, M>), dim3(grid), dim3(FUSED_THREADS), cv.total, stream, num,
                      cat, rows, L, D, cv, partials, slabs);
   return hipGetLastError();
 }
 
 template <int NB, int NBB>
-hipError_t launch_mp(int mp, const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
+hipError_t launch_m(int m, const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                      const CatDevice &D, const FusedCarve &cv, int grid, double *partials,
                      unsigned *slabs, hipStream_t stream) {
-  switch (mp) {
-#define CASE(MP) case MP: if constexpr (MP * NBB <= FUSED_MAX_SBLOCKS) return launch_one<NB, NBB, MP>(num, cat, rows, L, D, cv, grid, partials, slabs, stream); else break;
+  switch (m) {
+#define CASE(M_) case M_: if constexpr (((M_ + 1) / 2) * NBB <= FUSED_MAX_SBLOCKS) return launch_one<NB, NBB, M_>(num, cat, rows, L, D, cv, grid, partials, slabs, stream); else break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
     default: break;
@@ -471,7 +518,7 @@ bool fused_applicable(const CatLayout &L, const int32_t *nkeys, size_t lds_limit
   for (int c = 0; c < L.m; c++)
     if (nkeys[c] > 16 || L.kc[c] != 16) return false;
   const int nb = (L.n + 3) / 4, nbb = (3 * L.n + 31) / 32, mp = (L.m + 1) / 2;
-  if (mp * nbb > FUSED_MAX_SBLOCKS) return false;
+  if (mp * nbb > FUSED_MAX_SBLOCKS || L.m > 10) return false;
   const FusedCarve cv = make_carve(L, nb);
   if (lds_bytes) *lds_bytes = (size_t)cv.total;
   return (size_t)cv.total <= lds_limit;
@@ -480,10 +527,10 @@ bool fused_applicable(const CatLayout &L, const int32_t *nkeys, size_t lds_limit
 int fused_grid(const CatLayout &L, int cus, int partials_cap_wgs, uint64_t rows) {
   const FusedCarve cv = make_carve(L, (L.n + 3) / 4);
   int per_cu = (int)((160 * 1024) / (size_t)cv.total);
-  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);      // __launch_bounds__(256, 2): two per CU
+  per_cu = 1;                                               // 12 waves of up to 168 registers fill a CU
   int grid = cus * per_cu;
   if (grid > partials_cap_wgs) grid = partials_cap_wgs;
-  const uint64_t ntiles = (rows + TR - 1) / TR;
+  const uint64_t ntiles = rows / TR;
   if ((uint64_t)grid > ntiles) grid = (int)ntiles;
   return grid;
 }
@@ -496,11 +543,11 @@ hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, c
                         const CatDevice &D, int grid, double *partials, unsigned *pair_slabs,
                         double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   if (rows == 0) return hipSuccess;
-  const int nb = (L.n + 3) / 4, nbb = (3 * L.n + 31) / 32, mp = (L.m + 1) / 2;
+  const int nb = (L.n + 3) / 4, nbb = (3 * L.n + 31) / 32;
   const FusedCarve cv = make_carve(L, nb);
   hipError_t e = hipErrorInvalidValue;
   if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
-#define GO(NB_, NBB_) e = launch_mp<NB_, NBB_>(mp, num, cat, rows, L, D, cv, grid, partials, pair_slabs, stream)
+#define GO(NB_, NBB_) e = launch_m<NB_, NBB_>(L.m, num, cat, rows, L, D, cv, grid, partials, pair_slabs, stream)
   if (nbb == 1) {
     switch (nb) { case 1: GO(1, 1); break; case 2: GO(2, 1); break; case 3: GO(3, 1); break; default: break; }
   } else {
