@@ -227,25 +227,80 @@ cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t r
   return COFACTOR_OK;
 }
 
+// Splits the categorical tables of one update into launches whose tables fit the LDS budget:
+// counts + sums first, then runs of consecutive pair tables; a pair table that does not fit on its
+// own is updated in HBM (global atomics), all such pairs in one last launch.
+void plan_cat_passes(const CatLayout &L, size_t lds_budget, std::vector<CatPass> &lds_passes,
+                     CatPass &hbm_pass, bool &hbm_needed) {
+  lds_passes.clear();
+  hbm_needed = false;
+  hbm_pass = CatPass{};
+  const size_t dict = (size_t)L.n_slots * 12;
+  const bool dict_lds = dict <= lds_budget / 2;
+  const size_t budget = dict_lds ? lds_budget - dict : lds_budget;
+  hbm_pass.dict_lds = dict_lds && dict <= 48 * 1024;
+  const int npairs = L.kind == 0 ? L.m * (L.m + 1) / 2 : 0;
+  std::vector<int> c1_of(npairs), c2_of(npairs);
+  for (int c1 = 0, q = 0; c1 < L.m; c1++)
+    for (int c2 = c1; c2 < L.m && q < npairs; c2++, q++) { c1_of[q] = c1; c2_of[q] = c2; }
+  auto fresh = [&]() { CatPass p{}; p.dict_lds = dict_lds; p.p_base = 0; p.p_cells = 0; return p; };
+  // counts (+ sums)
+  const size_t base_bytes = (size_t)L.n_cnt * 4 + (L.kind == 0 ? (size_t)L.n_s * 8 : 0);
+  CatPass cur = fresh();
+  size_t used = 0;
+  bool cur_open = false;
+  if (base_bytes <= budget) {
+    cur.do_cnt = 1; cur.do_s = L.kind == 0; cur.col_mask = (L.m >= 32) ? 0xFFFFFFFFu : ((1u << L.m) - 1u);
+    used = base_bytes; cur_open = true;
+  } else {
+    hbm_pass.do_cnt = 1; hbm_pass.do_s = L.kind == 0;
+    hbm_pass.col_mask = (1u << L.m) - 1u;
+    hbm_needed = true;
+  }
+  for (int q = 0; q < npairs; q++) {
+    const size_t cells = (size_t)L.kc[c1_of[q]] * (size_t)L.kc[c2_of[q]];
+    const size_t bytes = cells * 4;
+    if (bytes > budget) {                         // too big for LDS on its own
+      hbm_pass.pair_mask[q >> 5] |= 1u << (q & 31);
+      hbm_pass.col_mask |= (1u << c1_of[q]) | (1u << c2_of[q]);
+      hbm_needed = true;
+      if (cur_open && cur.p_cells > 0) { lds_passes.push_back(cur); cur = fresh(); used = 0; cur_open = false; }
+      continue;
+    }
+    if (cur_open && used + bytes > budget) { lds_passes.push_back(cur); cur = fresh(); used = 0; cur_open = false; }
+    if (!cur_open) { cur = fresh(); used = 0; cur_open = true; }
+    if (cur.p_cells == 0) cur.p_base = L.p_off[q];
+    cur.pair_mask[q >> 5] |= 1u << (q & 31);
+    cur.col_mask |= (1u << c1_of[q]) | (1u << c2_of[q]);
+    cur.p_cells += (int)cells;
+    used += bytes;
+  }
+  if (cur_open) lds_passes.push_back(cur);
+}
+
 cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows,
                                bool timed = true) {
   hipStream_t st = a->ctx->stream;
-  const size_t lds = cat_lds_bytes(a->L);
-  const bool lds_tables = lds <= a->ctx->lds_budget;
-#ifdef COFACTOR_DEV_ABLATE
-  {
-    int32_t mask = (int32_t)env_long("COFACTOR_CAT_ABLATE", 0);
-    HIP_TRY(hipMemcpyAsync(a->D.flags + 2, &mask, sizeof(mask), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  }
-#endif
+  std::vector<CatPass> passes;
+  CatPass hbm{};
+  bool hbm_needed = false;
+  plan_cat_passes(a->L, a->ctx->lds_budget, passes, hbm, hbm_needed);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (a->ctx->profiling && timed) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     a->ctx->cat_ev.emplace_back(e0, e1);
   }
-  HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, lds_tables, a->ctx->cat_grid, st, e0, e1));
+  const size_t launches = passes.size() + (hbm_needed ? 1 : 0);
+  size_t i = 0;
+  for (auto const &P : passes) {
+    HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, P, true, a->ctx->cat_grid, st,
+                                  i == 0 ? e0 : nullptr, i + 1 == launches ? e1 : nullptr));
+    i++;
+  }
+  if (hbm_needed)
+    HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, hbm, false, a->ctx->cat_grid, st,
+                                  i == 0 ? e0 : nullptr, e1));
   return COFACTOR_OK;
 }
 

@@ -179,32 +179,38 @@ __device__ __forceinline__ int lookup_code(SlotPtr slots, CodePtr codes, int cap
   return -1;
 }
 
+// One launch accumulates the tables named by `P`: the counts, the per-key sums, and the pair tables
+// whose bit is set in P.pair_mask.  The host splits an update into passes whose tables fit LDS
+// (api.cpp: plan_cat_passes); tables too big for LDS are updated with global atomics.
 // MT > 0: the number of categorical columns is the compile-time constant MT (straight-line
 // atomics, no per-column branches); MT == 0: generic variant that reads m from the layout.
 template <bool LDS_TABLES, int KIND, int MT>
 __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num, CatCols cat,
                                                                      uint64_t rows, CatLayout L,
-                                                                     CatDevice D) {
+                                                                     CatDevice D, CatPass P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  // LDS carve (LDS_TABLES only): slots (8 B) | sums (8 B) | codes | counts | pairs (4 B each)
+  // LDS carve: [dictionary slots (8 B) | sums (8 B) | dictionary codes | counts | pairs (4 B each)]
+  const int d_slots = P.dict_lds ? L.n_slots : 0;
+  const int t_s = (LDS_TABLES && KIND == 0 && P.do_s) ? L.n_s : 0;
+  const int t_cnt = (LDS_TABLES && P.do_cnt) ? L.n_cnt : 0;
+  const int t_p = (LDS_TABLES && KIND == 0) ? P.p_cells : 0;
   unsigned long long *l_slot = reinterpret_cast<unsigned long long *>(lds_raw);
-  double *l_s = reinterpret_cast<double *>(l_slot + L.n_slots);
-  int32_t *l_code = reinterpret_cast<int32_t *>(l_s + (KIND == 0 ? L.n_s : 0));
-  unsigned *l_cnt = reinterpret_cast<unsigned *>(l_code + L.n_slots);
-  unsigned *l_p = l_cnt + L.n_cnt;
+  double *l_s = reinterpret_cast<double *>(l_slot + d_slots);
+  int32_t *l_code = reinterpret_cast<int32_t *>(l_s + t_s);
+  unsigned *l_cnt = reinterpret_cast<unsigned *>(l_code + d_slots);
+  unsigned *l_p = l_cnt + t_cnt;
   constexpr int MC = MT > 0 ? MT : COFACTOR_MAX_CAT;       // unroll bound
   const int m = MT > 0 ? MT : L.m;
 
   const int tid = threadIdx.x;
-  if (LDS_TABLES) {
-    for (int i = tid; i < L.n_slots; i += CAT_THREADS) { l_slot[i] = D.ht_slot[i]; l_code[i] = D.ht_code[i]; }
-    for (int i = tid; i < L.n_cnt; i += CAT_THREADS) l_cnt[i] = 0u;
-    if (KIND == 0) {
-      for (int i = tid; i < L.n_s; i += CAT_THREADS) l_s[i] = 0.0;
-      for (int i = tid; i < L.n_p; i += CAT_THREADS) l_p[i] = 0u;
-    }
-    __syncthreads();
-  }
+  for (int i = tid; i < d_slots; i += CAT_THREADS) { l_slot[i] = D.ht_slot[i]; l_code[i] = D.ht_code[i]; }
+  for (int i = tid; i < t_cnt; i += CAT_THREADS) l_cnt[i] = 0u;
+  for (int i = tid; i < t_s; i += CAT_THREADS) l_s[i] = 0.0;
+  for (int i = tid; i < t_p; i += CAT_THREADS) l_p[i] = 0u;
+  __syncthreads();
+  // dictionary through generic pointers: LDS copy when it fits, HBM otherwise
+  const unsigned long long *dict_slot = P.dict_lds ? l_slot : D.ht_slot;
+  const int32_t *dict_code = P.dict_lds ? l_code : D.ht_code;
 
 #ifdef COFACTOR_DEV_ABLATE   // timing experiments only (results are wrong when a bit is set)
   const int ablate = D.flags[2];
@@ -212,25 +218,25 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
   constexpr int ablate = 0;
 #endif
   const int n = L.n;
+  const bool do_s = KIND == 0 && P.do_s && !(ablate & 2);
   const uint64_t stride = (uint64_t)gridDim.x * CAT_THREADS;
   for (uint64_t r = (uint64_t)blockIdx.x * CAT_THREADS + tid; r < rows; r += stride) {
     int32_t key[MC];
 #pragma unroll
     for (int c = 0; c < MC; c++)
-      if (c < m) key[c] = cat.p[c][r];                      // all loads first, then the probes
-    float xk = (KIND == 0 && n > 0) ? num.p[0][r] : 0.f;
+      if (c < m && ((P.col_mask >> c) & 1u)) key[c] = cat.p[c][r];   // all loads first, then the probes
+    float xk = (do_s && n > 0) ? num.p[0][r] : 0.f;
     int code[MC];
     bool known = true;
 #pragma unroll
     for (int c = 0; c < MC; c++) {
-      if (c < m) {
-        if (LDS_TABLES) code[c] = lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], key[c]);
-        else code[c] = lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], key[c]);
+      if (c < m && ((P.col_mask >> c) & 1u)) {
+        code[c] = lookup_code(dict_slot + L.ht_off[c], dict_code + L.ht_off[c], L.ht_cap[c], key[c]);
         known = known && code[c] >= 0 && code[c] < L.kc[c];
       }
     }
     if (!known) { D.flags[1] = 1; continue; }               // never index a table with a bad code
-    if (!(ablate & 1)) {
+    if (P.do_cnt && !(ablate & 1)) {
 #pragma unroll
       for (int c = 0; c < MC; c++) {
         if (c < m) {
@@ -247,15 +253,17 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
 #pragma unroll
           for (int c2 = c1; c2 < MC; c2++) {
             if (c2 < m) {
-              const int idx = L.p_off[q] + code[c1] * L.kc[c2] + code[c2];
-              if (LDS_TABLES) atomicAdd(&l_p[idx], 1u);
-              else atomicAdd(&D.p[idx], 1ull);
+              if ((P.pair_mask[q >> 5] >> (q & 31)) & 1u) {
+                const int idx = L.p_off[q] + code[c1] * L.kc[c2] + code[c2];
+                if (LDS_TABLES) atomicAdd(&l_p[idx - P.p_base], 1u);
+                else atomicAdd(&D.p[idx], 1ull);
+              }
               q++;
             }
           }
         }
       }
-      if (!(ablate & 2)) {
+      if (do_s) {
         int sidx[MC];
 #pragma unroll
         for (int c = 0; c < MC; c++)
@@ -277,36 +285,34 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
 
   if (LDS_TABLES) {
     __syncthreads();
-    for (int i = tid; i < L.n_cnt; i += CAT_THREADS)
+    for (int i = tid; i < t_cnt; i += CAT_THREADS)
       if (l_cnt[i]) atomicAdd(&D.cnt[i], (unsigned long long)l_cnt[i]);
-    if (KIND == 0) {
-      for (int i = tid; i < L.n_s; i += CAT_THREADS)
-        if (l_s[i] != 0.0) unsafeAtomicAdd(&D.s[i], l_s[i]);
-      for (int i = tid; i < L.n_p; i += CAT_THREADS)
-        if (l_p[i]) atomicAdd(&D.p[i], (unsigned long long)l_p[i]);
-    }
+    for (int i = tid; i < t_s; i += CAT_THREADS)
+      if (l_s[i] != 0.0) unsafeAtomicAdd(&D.s[i], l_s[i]);
+    for (int i = tid; i < t_p; i += CAT_THREADS)
+      if (l_p[i]) atomicAdd(&D.p[P.p_base + i], (unsigned long long)l_p[i]);
   }
 }
 
 template <bool LT, int K, int MT>
 hipError_t launch_acc(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
-                      const CatDevice &D, int grid, size_t lds, hipStream_t stream) {
+                      const CatDevice &D, const CatPass &P, int grid, size_t lds, hipStream_t stream) {
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)cat_accumulate_kernel<LT, K, MT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((cat_accumulate_kernel<LT, K, MT>), dim3(grid), dim3(CAT_THREADS), lds, stream,
-                     num, cat, rows, L, D);
+                     num, cat, rows, L, D, P);
   return hipGetLastError();
 }
 
-template <int K>
-hipError_t launch_acc_lds(int m, const NumCols &num, const CatCols &cat, uint64_t rows,
-                          const CatLayout &L, const CatDevice &D, int grid, size_t lds,
-                          hipStream_t stream) {
+template <bool LT, int K>
+hipError_t launch_acc_m(int m, const NumCols &num, const CatCols &cat, uint64_t rows,
+                        const CatLayout &L, const CatDevice &D, const CatPass &P, int grid, size_t lds,
+                        hipStream_t stream) {
   switch (m) {
-#define CASE(M) case M: return launch_acc<true, K, M>(num, cat, rows, L, D, grid, lds, stream);
+#define CASE(M) case M: return launch_acc<LT, K, M>(num, cat, rows, L, D, P, grid, lds, stream);
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
     CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
 #undef CASE
@@ -316,9 +322,13 @@ hipError_t launch_acc_lds(int m, const NumCols &num, const CatCols &cat, uint64_
 
 }  // namespace
 
-size_t cat_lds_bytes(const CatLayout &L) {
-  size_t b = (size_t)L.n_slots * (8 + 4) + (size_t)L.n_cnt * 4;
-  if (L.kind == 0) b += (size_t)L.n_s * 8 + (size_t)L.n_p * 4;
+size_t cat_pass_lds_bytes(const CatLayout &L, const CatPass &P, bool lds_tables) {
+  size_t b = P.dict_lds ? (size_t)L.n_slots * (8 + 4) : 0;
+  if (lds_tables) {
+    if (P.do_cnt) b += (size_t)L.n_cnt * 4;
+    if (L.kind == 0 && P.do_s) b += (size_t)L.n_s * 8;
+    if (L.kind == 0) b += (size_t)P.p_cells * 4;
+  }
   return b;
 }
 
@@ -362,21 +372,21 @@ hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, con
 }
 
 hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
-                                 const CatLayout &L, const CatDevice &D, bool lds_tables, int grid,
-                                 hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                                 const CatLayout &L, const CatDevice &D, const CatPass &P,
+                                 bool lds_tables, int grid, hipStream_t stream, hipEvent_t ev0,
+                                 hipEvent_t ev1) {
   if (rows == 0 || L.m == 0) return hipSuccess;
   const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
   if ((uint64_t)grid > need) grid = (int)need;
-  const size_t lds = lds_tables ? cat_lds_bytes(L) : 0;
+  const size_t lds = cat_pass_lds_bytes(L, P, lds_tables);
   if (ev0) { hipError_t e = hipEventRecord(ev0, stream); if (e != hipSuccess) return e; }
   hipError_t le;
-  if (lds_tables) {
-    le = L.kind == 0 ? launch_acc_lds<0>(L.m, num, cat, rows, L, D, grid, lds, stream)
-                     : launch_acc_lds<1>(L.m, num, cat, rows, L, D, grid, lds, stream);
-  } else {
-    le = L.kind == 0 ? launch_acc<false, 0, 0>(num, cat, rows, L, D, grid, 0, stream)
-                     : launch_acc<false, 1, 0>(num, cat, rows, L, D, grid, 0, stream);
-  }
+  if (lds_tables)
+    le = L.kind == 0 ? launch_acc_m<true, 0>(L.m, num, cat, rows, L, D, P, grid, lds, stream)
+                     : launch_acc_m<true, 1>(L.m, num, cat, rows, L, D, P, grid, lds, stream);
+  else
+    le = L.kind == 0 ? launch_acc_m<false, 0>(L.m, num, cat, rows, L, D, P, grid, lds, stream)
+                     : launch_acc_m<false, 1>(L.m, num, cat, rows, L, D, P, grid, lds, stream);
   if (le != hipSuccess) return le;
   if (ev1) return hipEventRecord(ev1, stream);
   return hipSuccess;

@@ -72,15 +72,23 @@ struct CatDevice {
   unsigned long long *p;
 };
 
-size_t cat_lds_bytes(const CatLayout &L);
+// What one cat_accumulate launch updates.
+struct CatPass {
+  unsigned pair_mask[(MAX_PAIRS + 31) / 32];  // pair tables of this pass
+  unsigned col_mask;                          // key columns the pass has to read
+  int do_cnt, do_s;                           // counts / per-key sums in this pass
+  int p_base, p_cells;                        // LDS pair tables cover cells [p_base, p_base + p_cells)
+  int dict_lds;                               // dictionaries are copied to LDS
+};
+size_t cat_pass_lds_bytes(const CatLayout &L, const CatPass &P, bool lds_tables);
 
 hipError_t launch_cat_insert(const CatCols &cols, uint64_t rows, const CatLayout &L,
                              const CatDevice &D, hipStream_t stream);
 hipError_t launch_cat_assign_codes(const CatLayout &L, const CatDevice &D, hipStream_t stream);
 hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
-                                 const CatLayout &L, const CatDevice &D, bool lds_tables, int grid,
-                                 hipStream_t stream, hipEvent_t ev0 = nullptr,
-                                 hipEvent_t ev1 = nullptr);
+                                 const CatLayout &L, const CatDevice &D, const CatPass &P,
+                                 bool lds_tables, int grid, hipStream_t stream,
+                                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // re-inserts every (key, code) of the old dictionary into the new one (dictionary growth)
 hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
                              const CatDevice &Dnew, hipStream_t stream);
