@@ -62,6 +62,9 @@ struct cofactor_ctx {
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev, fused_ev;
   bool allow_fused = true;      // COFACTOR_NO_FUSED=1 forces the two-kernel path
+  bool allow_optimistic = true; // COFACTOR_NO_OPTIMISTIC=1: always run the dictionary pass first
+  unsigned *skip = nullptr;     // optimistic fused pass: [count, tile ids...]
+  size_t skip_bytes = 0;
   size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
 };
 
@@ -305,15 +308,29 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
 }
 
 cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const CatCols &cat,
-                                   uint64_t rows) {
+                                   uint64_t rows, bool allow_optimistic = true) {
   if (rows == 0) return COFACTOR_OK;
   cofactor_ctx *ctx = a->ctx;
   hipStream_t st = ctx->stream;
-  bool fused = false;
-  if (a->m > 0) {
+  bool aligned = rows >= FUSED_TILE_ROWS;        // the fused kernel wants whole tiles of aligned columns
+  for (int k = 0; k < a->n; k++) aligned = aligned && (reinterpret_cast<uintptr_t>(num.p[k]) & 15) == 0;
+  for (int c = 0; c < a->m; c++) aligned = aligned && (reinterpret_cast<uintptr_t>(cat.p[c]) & 15) == 0;
+  const uint64_t main_rows = rows - rows % FUSED_TILE_ROWS;
+
+  // Optimistic mode: when every column already has a dictionary that fits the fused kernel, skip
+  // the dictionary pass; the kernel leaves out (and lists) the tiles that meet an unknown key, and
+  // only those are redone below after a dictionary pass over them.
+  bool optimistic = allow_optimistic && ctx->allow_fused && ctx->allow_optimistic && a->m > 0 && aligned &&
+                    a->cat_ready;
+  if (optimistic) {
+    for (int c = 0; c < a->m; c++) optimistic = optimistic && a->nkeys_host[c] >= 1;
+    optimistic = optimistic && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
+  }
+  bool fused = optimistic;
+  if (a->m > 0 && !optimistic) {
     cofactor_status s = cat_dictionaries(a, cat, rows);
     if (s != COFACTOR_OK) return s;
-    fused = ctx->allow_fused && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
+    fused = ctx->allow_fused && aligned && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
   }
 #ifdef COFACTOR_DEV_ABLATE
   if (a->m > 0) {
@@ -322,14 +339,9 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
     HIP_TRY(hipStreamSynchronize(st));
   }
 #endif
-  if (fused) {                                    // whole tiles of aligned columns only
-    for (int k = 0; k < a->n; k++) fused = fused && (reinterpret_cast<uintptr_t>(num.p[k]) & 15) == 0;
-    for (int c = 0; c < a->m; c++) fused = fused && (reinterpret_cast<uintptr_t>(cat.p[c]) & 15) == 0;
-    fused = fused && rows >= FUSED_TILE_ROWS;
-  }
   uint64_t done = 0;
+  unsigned skipped = 0;
   if (fused) {                                    // one pass: dense + categorical
-    const uint64_t main_rows = rows - rows % FUSED_TILE_ROWS;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profiling) {
       HIP_TRY(hipEventCreate(&e0));
@@ -346,9 +358,46 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       HIP_TRY(hipMalloc((void **)&ctx->pair_slabs, slab));
       ctx->pair_slab_bytes = slab;
     }
-    HIP_TRY(launch_fused(num, cat, main_rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, a->d_acc, st,
-                         e0, e1));
+    unsigned *skip = nullptr;
+    if (optimistic) {
+      const size_t need = (main_rows / FUSED_TILE_ROWS + 1) * sizeof(unsigned);
+      if (need > ctx->skip_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(ctx->skip);
+        ctx->skip = nullptr;
+        ctx->skip_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->skip, need));
+        ctx->skip_bytes = need;
+      }
+      skip = ctx->skip;
+      HIP_TRY(hipMemsetAsync(skip, 0, sizeof(unsigned), st));
+    }
+    HIP_TRY(launch_fused(num, cat, main_rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, skip,
+                         a->d_acc, st, e0, e1));
     done = main_rows;
+    if (optimistic) {
+      HIP_TRY(hipMemcpyAsync(&skipped, skip, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
+  if (skipped > 0) {                              // redo the left-out tiles, dictionary pass included
+    const uint64_t trows = (uint64_t)skipped * FUSED_TILE_ROWS;
+    unsigned *temp = nullptr;
+    HIP_TRY(hipMalloc((void **)&temp, sizeof(unsigned) * trows * (size_t)(a->n + a->m)));
+    hipError_t ge = launch_gather_tiles(num, cat, a->n, a->m, ctx->skip + 1, skipped, temp, trows, st);
+    cofactor_status s = ge == hipSuccess ? COFACTOR_OK : hip_fail(ge, "launch_gather_tiles");
+    if (s == COFACTOR_OK) {
+      NumCols gnum{};
+      CatCols gcat{};
+      for (int k = 0; k < a->n; k++) gnum.p[k] = reinterpret_cast<const float *>(temp) + (size_t)k * trows;
+      for (int c = 0; c < a->m; c++) gcat.p[c] = reinterpret_cast<const int32_t *>(temp) + (size_t)(a->n + c) * trows;
+      const double before = a->dev_rows;
+      s = update_device_impl(a, gnum, gcat, trows, /*allow_optimistic=*/false);
+      a->dev_rows = before;                       // these rows are counted once, below
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(temp);
+    if (s != COFACTOR_OK) return s;
   }
   if (done < rows) {                              // two-kernel path (all rows, or the < 256-row tail)
     NumCols tnum = num;
@@ -356,6 +405,10 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
     for (int k = 0; k < a->n; k++) tnum.p[k] = num.p[k] + done;
     for (int c = 0; c < a->m; c++) tcat.p[c] = cat.p[c] + done;
     const uint64_t trows = rows - done;
+    if (optimistic) {                             // the tail's keys have not been through a dictionary pass
+      cofactor_status s = cat_dictionaries(a, tcat, trows);
+      if (s != COFACTOR_OK) return s;
+    }
     if (a->n > 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (ctx->profiling && !fused) {
@@ -524,6 +577,7 @@ cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   if (prop.sharedMemPerBlock > 0) ctx->lds_max = prop.sharedMemPerBlock;
   if (ctx->lds_budget > ctx->lds_max) ctx->lds_budget = ctx->lds_max;
   ctx->allow_fused = env_long("COFACTOR_NO_FUSED", 0) == 0;
+  ctx->allow_optimistic = env_long("COFACTOR_NO_OPTIMISTIC", 0) == 0;
   HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)ctx->gram_grid * GRAM_ACC_LEN));
   *out = ctx.release();
   return COFACTOR_OK;
@@ -536,6 +590,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)cofactor_ctx_profile_read(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   (void)hipFree(ctx->partials);
   (void)hipFree(ctx->pair_slabs);
+  (void)hipFree(ctx->skip);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -107,7 +107,8 @@ template <int NB, int NBB, int M>
 __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCols cat, uint64_t rows,
                                                               CatLayout L, CatDevice D, FusedCarve cv,
                                                               double *__restrict__ partials,
-                                                              unsigned *__restrict__ pair_slabs) {
+                                                              unsigned *__restrict__ pair_slabs,
+                                                              unsigned *__restrict__ skip) {
   constexpr int NPAIR = NB * (NB + 1) / 2;
   constexpr int NBC = 4 * NB;
   constexpr int MP = (M + 1) / 2;                          // key columns are processed in pairs by the MFMA team
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   unsigned *l_cnt = reinterpret_cast<unsigned *>(lds + cv.cnt);
   unsigned *l_p = reinterpret_cast<unsigned *>(lds + cv.pairs);   // two 16-bit cells per dword
   unsigned *l_nf = reinterpret_cast<unsigned *>(lds + cv.nf);     // [buffer]: stamp of a tile holding inf / nan
+  unsigned *l_skip = l_nf + 2;                                    // [buffer]: stamp of a tile with an unknown key
   auto xt_of = [&](int b) { return reinterpret_cast<float *>(lds + cv.xt + b * cv.xt_stride); };
   auto pt_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.pt + b * cv.pt_stride); };
   auto codes_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.codes + b * cv.codes_stride); };
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   for (int i = tid; i < L.n_cnt; i += FUSED_THREADS) l_cnt[i] = 0u;
   for (int i = tid; i < L.n_s; i += FUSED_THREADS) l_s[i] = 0.0;
   for (int i = tid; i < n_pw; i += FUSED_THREADS) l_p[i] = 0u;
-  if (tid < 2) l_nf[tid] = 0u;
+  if (tid < 4) l_nf[tid] = 0u;                               // l_nf[0..1], l_skip[0..1]
 
   // ---- lane roles of the MFMA team -------------------------------------------------------------
   int colA = NBC, colB = NBC;                              // Gram operand columns (gram.hip)
@@ -233,6 +235,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
         if (ablate & 8) packed = make_uint2((pre[i].x & 15u) | ((pre[i].y & 15u) << 16), (pre[i].z & 15u) | ((pre[i].w & 15u) << 16));
         else packed = lds_lookup4(slots, dc, cap, pre[i]);
         *reinterpret_cast<uint2 *>(&codes[c * PTS + 4 * lane]) = packed;
+        // optimistic mode (skip != nullptr): a tile that meets a key the dictionary does not
+        // know yet is left out as a whole and redone by the host after a dictionary pass
+        if (skip && ((packed.x & 0xFFFFu) == 0xFFFFu || (packed.x >> 16) == 0xFFFFu ||
+                     (packed.y & 0xFFFFu) == 0xFFFFu || (packed.y >> 16) == 0xFFFFu))
+          l_skip[b] = stamp;
       }
     }
   };
@@ -415,7 +422,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     unsigned k = 1;
     for (uint64_t t = blockIdx.x; t < ntiles; t += G) {
       if (since_p == P_FLUSH_TILES) { flush_pairs(); since_p = 0; }
-      count_rows(b, k);
+      if (l_skip[b] == k) {                                 // tile left out: remember it for the host
+        if (tt == 0) skip[1 + atomicAdd(&skip[0], 1u)] = (unsigned)t;
+      } else {
+        count_rows(b, k);
+      }
       since_p++;
       __syncthreads();
       b ^= 1; k++;
@@ -424,8 +435,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   } else {
     __syncthreads();
     int b = 0, since_g = 0, since_s = 0;
-    for (uint64_t t = blockIdx.x; t < ntiles; t += G) {
-      crunch(b);
+    unsigned k = 1;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += G, k++) {
+      if (l_skip[b] != k) crunch(b);
       if (++since_g == G_FLUSH_TILES) { flush_gram(); since_g = 0; }
       if (++since_s == S_FLUSH_TILES) { flush_s(); since_s = 0; }
       __syncthreads();
@@ -464,6 +476,21 @@ __global__ __launch_bounds__(256) void fused_pairs_fold_kernel(const unsigned *_
   if (total) p[cell] += total;
 }
 
+// temp[col][i * 256 + j] = col[list[i] * 256 + j]: the tiles the optimistic pass left out, packed
+__global__ __launch_bounds__(256) void gather_tiles_kernel(NumCols num, CatCols cat, int n, int m,
+                                                           const unsigned *__restrict__ list, unsigned count,
+                                                           unsigned *__restrict__ temp, uint64_t temp_stride) {
+  for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
+    const uint64_t src = (uint64_t)list[i] * TR + threadIdx.x;
+    const uint64_t dst = (uint64_t)i * TR + threadIdx.x;
+    for (int c = 0; c < n + m; c++) {
+      const unsigned *col = c < n ? reinterpret_cast<const unsigned *>(num.p[c])
+                                  : reinterpret_cast<const unsigned *>(cat.p[c - n]);
+      temp[(uint64_t)c * temp_stride + dst] = col[src];
+    }
+  }
+}
+
 FusedCarve make_carve(const CatLayout &L, int nb) {
   const int nbb = (3 * L.n + 31) / 32;
   FusedCarve c{};
@@ -480,7 +507,7 @@ FusedCarve make_carve(const CatLayout &L, int nb) {
   c.dcode = take((size_t)L.n_slots * 4, 4);
   c.cnt = take((size_t)L.n_cnt * 4, 4);
   c.pairs = take((size_t)((L.n_p + 1) / 2) * 4, 4);
-  c.nf = take(8, 4);
+  c.nf = take(16, 4);
   c.gsum = take(sizeof(double) * 4 * GRAM_ACC_LEN, 8);
   c.total = (int)((o + 15) / 16 * 16);
   return c;
@@ -489,21 +516,21 @@ FusedCarve make_carve(const CatLayout &L, int nb) {
 template <int NB, int NBB, int M>
 hipError_t launch_one(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                       const CatDevice &D, const FusedCarve &cv, int grid, double *partials,
-                      unsigned *slabs, hipStream_t stream) {
+                      unsigned *slabs, unsigned *skip, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute((const void *)fused_kernel<NB, NBB, M>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, cv.total);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((fused_kernel<NB, NBB, M>), dim3(grid), dim3(FUSED_THREADS), cv.total, stream, num,
-                     cat, rows, L, D, cv, partials, slabs);
+                     cat, rows, L, D, cv, partials, slabs, skip);
   return hipGetLastError();
 }
 
 template <int NB, int NBB>
 hipError_t launch_m(int m, const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                      const CatDevice &D, const FusedCarve &cv, int grid, double *partials,
-                     unsigned *slabs, hipStream_t stream) {
+                     unsigned *slabs, unsigned *skip, hipStream_t stream) {
   switch (m) {
-#define CASE(M_) case M_: if constexpr (((M_ + 1) / 2) * NBB <= FUSED_MAX_SBLOCKS) return launch_one<NB, NBB, M_>(num, cat, rows, L, D, cv, grid, partials, slabs, stream); else break;
+#define CASE(M_) case M_: if constexpr (((M_ + 1) / 2) * NBB <= FUSED_MAX_SBLOCKS) return launch_one<NB, NBB, M_>(num, cat, rows, L, D, cv, grid, partials, slabs, skip, stream); else break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
     default: break;
@@ -541,13 +568,14 @@ size_t fused_slab_bytes(const CatLayout &L, int grid) {
 
 hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                         const CatDevice &D, int grid, double *partials, unsigned *pair_slabs,
-                        double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                        unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0,
+                        hipEvent_t ev1) {
   if (rows == 0) return hipSuccess;
   const int nb = (L.n + 3) / 4, nbb = (3 * L.n + 31) / 32;
   const FusedCarve cv = make_carve(L, nb);
   hipError_t e = hipErrorInvalidValue;
   if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
-#define GO(NB_, NBB_) e = launch_m<NB_, NBB_>(L.m, num, cat, rows, L, D, cv, grid, partials, pair_slabs, stream)
+#define GO(NB_, NBB_) e = launch_m<NB_, NBB_>(L.m, num, cat, rows, L, D, cv, grid, partials, pair_slabs, skip, stream)
   if (nbb == 1) {
     switch (nb) { case 1: GO(1, 1); break; case 2: GO(2, 1); break; case 3: GO(3, 1); break; default: break; }
   } else {
@@ -561,6 +589,14 @@ hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, c
                      grid, cells_padded, L.n_p, D.p);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return launch_gram_fold(partials, grid, acc, stream);
+}
+
+hipError_t launch_gather_tiles(const NumCols &num, const CatCols &cat, int n, int m, const unsigned *list,
+                               unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_tiles_kernel, dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, num, cat,
+                     n, m, list, count, temp, temp_stride);
+  return hipGetLastError();
 }
 
 }  // namespace cofactor

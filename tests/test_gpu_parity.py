@@ -227,6 +227,42 @@ def test_keys_arriving_in_later_batches(ctx):
     agg.close()
 
 
+def test_optimistic_pass_redoes_tiles_with_new_keys(ctx):
+    """Second and later updates skip the dictionary pass; tiles that meet a key the dictionary
+    does not know are left out by the fused kernel and redone.  Batches: known keys only, a few
+    new keys in a few tiles, new keys everywhere (still <= 16 keys), then > 16 keys."""
+    import torch
+    rng = np.random.default_rng(99)
+    n, m, rows = 3, 3, 256 * 40 + 77
+    agg = ctx.aggregate(n, m)
+    ref = orc.State(orc.FAITHFUL)
+
+    def batch(make_keys):
+        num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+        cat = [make_keys().astype(np.int32) for _ in range(m)]
+        dn = [torch.from_numpy(c).cuda() for c in num]
+        dc = [torch.from_numpy(c).cuda() for c in cat]
+        torch.cuda.synchronize()
+        agg.update_device(dn, dc)
+        ref.update(num, cat)
+        assert blob_to_dict(agg.finalize()) == blob_to_dict(ref.finalize())
+
+    batch(lambda: rng.integers(0, 6, rows))                       # first update: dictionary pass
+    batch(lambda: rng.integers(0, 6, rows))                       # all keys known: nothing skipped
+
+    def few_new():
+        k = rng.integers(0, 6, rows)
+        k[256 * 7 + 3] = 100                                      # one new key in tile 7
+        k[256 * 31 + 200] = -5                                    # another in tile 31
+        k[rows - 1] = 77                                          # and one in the < 256-row tail
+        return k
+    batch(few_new)
+    batch(lambda: rng.integers(0, 14, rows))                      # new keys in every tile, <= 16 keys total? (6+3+...)
+    batch(lambda: rng.integers(0, 40, rows))                      # outgrows the fused kernel
+    batch(lambda: rng.integers(0, 40, rows))
+    agg.close()
+
+
 def test_mixed_random_floats_10_10(ctx):
     rng = np.random.default_rng(77)
     rows, n, m = 400_000, 10, 10
