@@ -78,6 +78,9 @@ struct cofactor_agg {
   bool cat_ready = false;
   bool cat_check_pending = false;
   int32_t nkeys_host[COFACTOR_MAX_CAT] = {0};
+  // finalize's two-call protocol: the blob of the size query is kept for the fill call
+  std::vector<double> blob_cache;
+  bool blob_cache_valid = false;
   CatLayout L{};
   CatDevice D{};
   // host staging for update_host (pinned) and its device mirror
@@ -310,6 +313,7 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
 cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const CatCols &cat,
                                    uint64_t rows, bool allow_optimistic = true) {
   if (rows == 0) return COFACTOR_OK;
+  a->blob_cache_valid = false;
   cofactor_ctx *ctx = a->ctx;
   hipStream_t st = ctx->stream;
   bool aligned = rows >= FUSED_TILE_ROWS;        // the fused kernel wants whole tiles of aligned columns
@@ -669,6 +673,7 @@ cofactor_status cofactor_agg_reset(cofactor_agg *a) {
   DeviceGuard guard(a->ctx->device);
   hipStream_t st = a->ctx->stream;
   a->host.clear();
+  a->blob_cache_valid = false;
   a->dev_rows = 0;
   a->stage_rows = 0;
   HIP_TRY(hipMemsetAsync(a->d_acc, 0, sizeof(double) * GRAM_ACC_LEN, st));
@@ -709,6 +714,7 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
   if ((a->n > 0 && !num) || (a->m > 0 && !cat)) return fail(COFACTOR_ERR_INVALID, "column array is null");
   if (rows == 0) return COFACTOR_OK;
+  a->blob_cache_valid = false;
   DeviceGuard guard(a->ctx->device);
   if (!a->stage_cap) {
     a->stage_cap = (uint64_t)env_long("COFACTOR_STAGE_ROWS", 1 << 18);
@@ -759,6 +765,7 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
 cofactor_status cofactor_agg_update_triples(cofactor_agg *a, const double *blobs,
                                             const uint64_t *offsets, uint64_t count) {
   if (!a || (count && (!blobs || !offsets))) return fail(COFACTOR_ERR_INVALID, "null argument");
+  a->blob_cache_valid = false;
   ListTriple t;
   std::string err;
   for (uint64_t i = 0; i < count; i++) {
@@ -777,18 +784,22 @@ cofactor_status cofactor_agg_combine(cofactor_agg *dst, cofactor_agg *src) {
   cofactor_status s = snapshot(src, snap);
   if (s != COFACTOR_OK) return s;
   std::string err;
+  dst->blob_cache_valid = false;
   if (!dst->host.add(snap, err)) return fail(COFACTOR_ERR_INVALID, err);
   return COFACTOR_OK;
 }
 
 cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap, uint64_t *needed) {
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
-  HostTriple snap;
-  cofactor_status s = snapshot(a, snap);
-  if (s != COFACTOR_OK) return s;
-  std::vector<double> blob;
-  snap.encode(blob);
-  return emit_blob(blob, out, cap, needed);
+  if (!a->blob_cache_valid || a->stage_rows > 0) {
+    HostTriple snap;
+    cofactor_status s = snapshot(a, snap);
+    if (s != COFACTOR_OK) return s;
+    a->blob_cache.clear();
+    snap.encode(a->blob_cache);
+    a->blob_cache_valid = true;
+  }
+  return emit_blob(a->blob_cache, out, cap, needed);
 }
 
 uint64_t cofactor_dense_len(int n_num, cofactor_kind kind) {
@@ -828,6 +839,7 @@ cofactor_status cofactor_agg_import_dense_device(cofactor_agg *a, const double *
   }
   HIP_TRY(hipStreamSynchronize(st));
   a->dev_rows = 0;
+  a->blob_cache_valid = false;
   a->host = std::move(snap);
   // 2. ... then replace its dense totals by the reduced ones
   a->host.N = v[0];
