@@ -273,6 +273,35 @@ def test_mixed_random_floats_10_10(ctx):
     assert_triple_close(got, want, rtol=RTOL)            # counts / keys exact inside
 
 
+def test_random_shapes_exact(ctx):
+    """Seeded sweep over shapes that land on every kernel combination (dense only, fused, fused +
+    tail, multi-pass LDS tables, HBM tables, NB kind): integer-valued tables, exact equality."""
+    import torch
+    rng = np.random.default_rng(2024)
+    for trial in range(48):
+        n = int(rng.integers(0, 21))
+        m = int(rng.integers(0, 21))
+        if n == 0 and m == 0:
+            n = 1
+        nb = bool(rng.integers(0, 4) == 0)
+        keys = int(rng.choice([2, 5, 16, 17, 40, 300]))
+        rows = int(rng.choice([1, 255, 256, 257, 1000, 4096, 10_007, 33_333]))
+        num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+        cat = [(rng.integers(0, keys, rows) * 3 - 7).astype(np.int32) for _ in range(m)]
+        agg = ctx.aggregate(n, m, cofactor_hip.NB if nb else cofactor_hip.TRIPLE)
+        ref = orc.State(orc.FAITHFUL)
+        for part in range(int(rng.integers(1, 3))):            # one or two updates into the same state
+            lo = 0 if part == 0 else rows // 3
+            dn = [torch.from_numpy(np.ascontiguousarray(c[lo:])).cuda() for c in num]
+            dc = [torch.from_numpy(np.ascontiguousarray(c[lo:])).cuda() for c in cat]
+            torch.cuda.synchronize()
+            agg.update_device(dn, dc)
+            ref.update([c[lo:] for c in num], [c[lo:] for c in cat], nb=nb)
+        got, want = blob_to_dict(agg.finalize()), blob_to_dict(ref.finalize())
+        agg.close()
+        assert got == want, (trial, n, m, nb, keys, rows)
+
+
 def test_nb_aggregate(ctx):
     rng = np.random.default_rng(21)
     rows = 30_000
