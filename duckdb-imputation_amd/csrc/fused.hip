@@ -50,7 +50,7 @@ __device__ __forceinline__ unsigned fhash(int32_t key, int cap) {
   return ((unsigned)key * 0x9E3779B1u) >> (32 - (31 - __builtin_clz(cap)));
 }
 
-// codes of 4 keys in the LDS copy of a dictionary (0xFFFF if absent), packed as 4 x u16.  The four
+// codes of 4 keys in the LDS copy of a dictionary (NO_CODE = 16 if absent), packed as 4 x u16.  The four
 // probe chains advance together, so their LDS round trips overlap.  One copy in the code object
 // (called 2.5 times per loader wave and tile): the loader loop has to stay small.
 __device__ __noinline__ uint2 lds_lookup4(const unsigned long long *slots, const int32_t *codes, int cap,
@@ -59,7 +59,7 @@ __device__ __noinline__ uint2 lds_lookup4(const unsigned long long *slots, const
   unsigned h[4], cd[4];
   bool open[4];
 #pragma unroll
-  for (int e = 0; e < 4; e++) { h[e] = fhash((int32_t)key[e], cap); open[e] = true; cd[e] = 0xFFFFu; }
+  for (int e = 0; e < 4; e++) { h[e] = fhash((int32_t)key[e], cap); open[e] = true; cd[e] = 16u; }   // NO_CODE
   for (int probe = 0; probe < cap; probe++) {
     unsigned long long cur[4];
 #pragma unroll
@@ -80,20 +80,20 @@ __device__ __noinline__ uint2 lds_lookup4(const unsigned long long *slots, const
   return make_uint2(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16));
 }
 
-// 8 u16 codes (uint4) -> 8 bf16 one-hot values for code value i: 1.0 (0x3F80) where equal
+// 8 u16 codes (uint4) -> 8 bf16 one-hot values for code value i: 1.0 (0x3F80) where equal.
+// Codes in the tile are 0..15, or NO_CODE = 16 for "no such key / no such column", and ii holds
+// i (0..15) in both halves, so d = code ^ i is 0..31 in each 16-bit half and 0 only on a match:
+// 0x20 - d has bit 5 set exactly there, with no borrow between the halves.  Plain 32-bit ops
+// (hipcc scalarises 16-bit vector compares into v_cmp/v_cndmask/v_perm chains).
+constexpr unsigned NO_CODE = 16u;
 __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
-  const u16x2 one = {1, 1}, neg = {0xC080, 0xC080}, pos = {0x3F80, 0x3F80};
-  uint4 o;
   unsigned w[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
   for (int e = 0; e < 4; e++) {
-    u16x2 d = __builtin_bit_cast(u16x2, w[e] ^ ii);
-    u16x2 t = __builtin_elementwise_min(d, one);          // 0 where equal, 1 elsewhere
-    u16x2 v = t * neg + pos;                              // 0x3F80 where equal, 0x10000 -> 0 elsewhere
-    w[e] = __builtin_bit_cast(unsigned, v);
+    const unsigned hit = (0x00200020u - (w[e] ^ ii)) & 0x00200020u;    // 0x20 per matching half
+    w[e] = __umul24(hit, 0x1FCu);                                         // 0x20 * 0x1FC = 0x3F80 = bf16 1.0
   }
-  o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-  return __builtin_bit_cast(bf16x8, o);
+  return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
 }
 
 constexpr int FUSED_THREADS = 768;      // waves 0-3 loaders, 4-7 counters, 8-11 MFMA team
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     for (int i = tid; i < (NBC + 1) * XCS; i += FUSED_THREADS) x[i] = 0.f;
     unsigned short *pz = pt_of(b);
     for (int i = tid; i < 32 * NBB * PTS; i += FUSED_THREADS) pz[i] = 0;   // piece columns >= 3n stay 0
-    for (int i = tid; i < (m + 1) * PTS; i += FUSED_THREADS) cd[i] = 0xFFFF;   // column m stays 0xFFFF
+    for (int i = tid; i < (m + 1) * PTS; i += FUSED_THREADS) cd[i] = (unsigned short)NO_CODE;   // column m stays NO_CODE
   }
   for (int i = tid; i < L.n_slots; i += FUSED_THREADS) { l_slot[i] = D.ht_slot[i]; l_dcode[i] = D.ht_code[i]; }
   for (int i = tid; i < L.n_cnt; i += FUSED_THREADS) l_cnt[i] = 0u;
@@ -237,8 +237,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
         *reinterpret_cast<uint2 *>(&codes[c * PTS + 4 * lane]) = packed;
         // optimistic mode (skip != nullptr): a tile that meets a key the dictionary does not
         // know yet is left out as a whole and redone by the host after a dictionary pass
-        if (skip && ((packed.x & 0xFFFFu) == 0xFFFFu || (packed.x >> 16) == 0xFFFFu ||
-                     (packed.y & 0xFFFFu) == 0xFFFFu || (packed.y >> 16) == 0xFFFFu))
+        if (skip && ((packed.x | packed.y) & 0x00100010u))  // some code is NO_CODE
           l_skip[b] = stamp;
       }
     }
@@ -374,7 +373,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
 #pragma unroll
         for (int p = 0; p < MP; p++) {
           int c = 2 * p + (r32 >> 4);
-          c = c < m ? c : m;                                // column m is all 0xFFFF: matches nothing
+          c = c < m ? c : m;                                // column m is all NO_CODE: matches nothing
           const uint4 cvv = *reinterpret_cast<const uint4 *>(&codes[c * PTS + row8]);
           const bf16x8 aop = onehot8(cvv, ii);
 #pragma unroll
