@@ -75,3 +75,65 @@ def test_subtract_unknown_key_is_reported_not_fatal(goldens):
     out = cofactor_hip.sub(g1, g2)          # g2 has keys g1 lacks: reported and skipped
     assert b"not present in first triple" in cofactor_hip.lib().cofactor_last_error()
     np.testing.assert_array_equal(out, orc.sub(g1, g2))
+
+
+def test_two_call_protocol_and_capacity_error(goldens):
+    """out == NULL reports the size; a too-small buffer is COFACTOR_ERR_CAPACITY, never a write."""
+    import ctypes as C
+    from triple_fmt import dict_to_blob
+    lib = cofactor_hip.lib()
+    exp = sorted(goldens["test_sum.py"]["tests"][1]["expected"], key=lambda e: e["row"])
+    a, b = dict_to_blob(exp[0]["value"]), dict_to_blob(exp[1]["value"])
+    need = C.c_uint64(0)
+    assert lib.cofactor_triple_add(a.ctypes.data, b.ctypes.data, None, 0, C.byref(need)) == cofactor_hip.OK
+    assert need.value > 4
+    small = np.full(4, -1.0)
+    st = lib.cofactor_triple_add(a.ctypes.data, b.ctypes.data, small.ctypes.data, small.size, C.byref(need))
+    assert st == cofactor_hip.ERR_CAPACITY and np.all(small == -1.0)
+    assert b"too small" in lib.cofactor_last_error()
+
+
+def test_malformed_blobs_are_rejected():
+    lib = cofactor_hip.lib()
+    bad_kind = np.array([2.0, 1, 0, 1, 0.5, 0.25])
+    ok = np.array([0.0, 1, 0, 1, 0.5, 0.25])
+    with pytest.raises(cofactor_hip.CofactorError) as e:
+        cofactor_hip.add(bad_kind, ok)
+    assert e.value.status == cofactor_hip.ERR_INVALID
+    nb = np.array([1.0, 1, 0, 1, 0.5, 0.25])
+    with pytest.raises(cofactor_hip.CofactorError):          # kinds differ
+        cofactor_hip.multiply(ok, nb)
+    with pytest.raises(cofactor_hip.CofactorError):
+        cofactor_hip.add(ok, nb)
+
+
+def test_null_arguments_do_not_crash():
+    import ctypes as C
+    lib = cofactor_hip.lib()
+    assert lib.cofactor_ctx_create(0, None) == cofactor_hip.ERR_INVALID
+    assert lib.cofactor_agg_create(None, 1, 0, 0, None) == cofactor_hip.ERR_INVALID
+    assert lib.cofactor_agg_finalize(None, None, 0, None) == cofactor_hip.ERR_INVALID
+    assert lib.cofactor_agg_combine(None, None) == cofactor_hip.ERR_INVALID
+    assert lib.cofactor_triple_multiply(None, None, None, 0, None) == cofactor_hip.ERR_INVALID
+    lib.cofactor_agg_destroy(None)          # no-ops
+    lib.cofactor_ctx_destroy(None)
+    assert lib.cofactor_blob_len(None) == 0
+    assert lib.cofactor_dense_len(20, 0) == 1 + 20 + 210 and lib.cofactor_dense_len(20, 1) == 41
+
+
+def test_multiply_matches_oracle_on_random_triples():
+    """multiply_triple beyond the 5-row goldens: random shapes, integer values (exact in float)."""
+    rng = np.random.default_rng(6)
+    for trial in range(20):
+        n1, m1, n2, m2 = (int(x) for x in rng.integers(0, 4, 4))
+        if n1 + m1 == 0: n1 = 1
+        if n2 + m2 == 0: m2 = 1
+        def table(n, m, rows):
+            return ([rng.integers(0, 5, rows).astype(np.float32) for _ in range(n)],
+                    [rng.integers(-2, 4, rows).astype(np.int32) for _ in range(m)])
+        for nb in (False, True):
+            A = orc.State(orc.FAITHFUL).update(*table(n1, m1, 7), nb=nb).finalize()
+            B = orc.State(orc.FAITHFUL).update(*table(n2, m2, 5), nb=nb).finalize()
+            np.testing.assert_array_equal(cofactor_hip.multiply(A, B), orc.multiply(A, B, orc.FAITHFUL))
+            if (n1, m1) == (n2, m2):
+                np.testing.assert_array_equal(cofactor_hip.add(A, B), orc.add(A, B, orc.FAITHFUL))
