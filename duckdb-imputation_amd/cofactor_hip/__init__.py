@@ -21,7 +21,8 @@ SYMBOLS = [
     "cofactor_ctx_create", "cofactor_ctx_destroy", "cofactor_ctx_synchronize", "cofactor_ctx_stream",
     "cofactor_ctx_profile_enable", "cofactor_ctx_profile_read",
     "cofactor_agg_create", "cofactor_agg_destroy", "cofactor_agg_reset",
-    "cofactor_agg_update_device", "cofactor_agg_update_host", "cofactor_agg_update_triples",
+    "cofactor_agg_update_device", "cofactor_agg_update_device_masked", "cofactor_agg_update_host",
+    "cofactor_agg_update_triples",
     "cofactor_agg_combine", "cofactor_agg_finalize",
     "cofactor_dense_len", "cofactor_agg_export_dense_device", "cofactor_agg_import_dense_device",
     "cofactor_lift_host", "cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub",
@@ -66,6 +67,7 @@ def lib():
         L.cofactor_agg_destroy.restype = None
         L.cofactor_agg_reset.argtypes = [vp]
         L.cofactor_agg_update_device.argtypes = [vp, pp, pp, u64]
+        L.cofactor_agg_update_device_masked.argtypes = [vp, pp, pp, vp, u64]
         L.cofactor_agg_update_host.argtypes = [vp, pp, pp, pp, pp, vp, u64]
         L.cofactor_agg_update_triples.argtypes = [vp, vp, vp, u64]
         L.cofactor_agg_combine.argtypes = [vp, vp]
@@ -179,6 +181,16 @@ class Aggregate:
             assert t.numel() == rows
         self.update_device_ptrs([t.data_ptr() for t in num_tensors],
                                 [t.data_ptr() for t in cat_tensors], rows or 0)
+
+    def update_device_masked(self, num_tensors, cat_tensors, mask):
+        """Like update_device, keeping only rows whose byte in `mask` (uint8 device tensor) is non-zero."""
+        assert str(mask.dtype) == "torch.uint8" and mask.is_cuda and mask.is_contiguous()
+        rows = mask.numel()
+        for t in list(num_tensors) + list(cat_tensors):
+            assert t.numel() == rows and t.is_cuda and t.is_contiguous()
+        _check(lib().cofactor_agg_update_device_masked(
+            self._h, _ptr_array([t.data_ptr() for t in num_tensors]),
+            _ptr_array([t.data_ptr() for t in cat_tensors]), mask.data_ptr(), rows))
 
     def update_host(self, num_cols, cat_cols, num_sel=None, cat_sel=None, row_idx=None, rows=None):
         """One DataChunk of host columns (numpy), optional per-column selection vectors and the

@@ -72,7 +72,9 @@ struct cofactor_agg {
   cofactor_ctx *ctx = nullptr;
   int n = 0, m = 0, kind = 0;
   HostTriple host;              // everything merged in on the host (combine, lifted triples, import)
-  double dev_rows = 0;          // rows whose contributions sit in the device tables
+  double dev_rows = 0;          // rows (of unmasked updates) whose contributions sit in the device tables
+  unsigned long long *d_kept = nullptr;   // device counter: rows kept by masked updates
+  bool dev_dirty = false;       // the device tables hold something
   double *d_acc = nullptr;      // dense accumulator image (GRAM_ACC_LEN doubles)
   // categorical device state
   bool cat_ready = false;
@@ -285,7 +287,7 @@ void plan_cat_passes(const CatLayout &L, size_t lds_budget, std::vector<CatPass>
 }
 
 cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows,
-                               bool timed = true) {
+                               bool timed = true, const uint8_t *mask = nullptr) {
   hipStream_t st = a->ctx->stream;
   std::vector<CatPass> passes;
   CatPass hbm{};
@@ -301,22 +303,24 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
   size_t i = 0;
   for (auto const &P : passes) {
     HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, P, true, a->ctx->cat_grid, st,
-                                  i == 0 ? e0 : nullptr, i + 1 == launches ? e1 : nullptr));
+                                  i == 0 ? e0 : nullptr, i + 1 == launches ? e1 : nullptr, mask));
     i++;
   }
   if (hbm_needed)
     HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, hbm, false, a->ctx->cat_grid, st,
-                                  i == 0 ? e0 : nullptr, e1));
+                                  i == 0 ? e0 : nullptr, e1, mask));
   return COFACTOR_OK;
 }
 
 cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const CatCols &cat,
-                                   uint64_t rows, bool allow_optimistic = true) {
+                                   uint64_t rows, bool allow_optimistic = true,
+                                   const uint8_t *mask = nullptr) {
   if (rows == 0) return COFACTOR_OK;
   a->blob_cache_valid = false;
+  a->dev_dirty = true;
   cofactor_ctx *ctx = a->ctx;
   hipStream_t st = ctx->stream;
-  bool aligned = rows >= FUSED_TILE_ROWS;        // the fused kernel wants whole tiles of aligned columns
+  bool aligned = rows >= FUSED_TILE_ROWS && !mask;   // the fused kernel wants whole tiles of aligned columns, no row mask
   for (int k = 0; k < a->n; k++) aligned = aligned && (reinterpret_cast<uintptr_t>(num.p[k]) & 15) == 0;
   for (int c = 0; c < a->m; c++) aligned = aligned && (reinterpret_cast<uintptr_t>(cat.p[c]) & 15) == 0;
   const uint64_t main_rows = rows - rows % FUSED_TILE_ROWS;
@@ -420,15 +424,17 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
         HIP_TRY(hipEventCreate(&e1));
         ctx->gram_ev.emplace_back(e0, e1);
       }
-      HIP_TRY(launch_gram(tnum, a->n, trows, ctx->gram_grid, ctx->partials, a->d_acc, st, e0, e1));
+      HIP_TRY(launch_gram(tnum, a->n, trows, ctx->gram_grid, ctx->partials, a->d_acc, st, e0, e1,
+                          mask ? mask + done : nullptr));
     }
     if (a->m > 0) {
-      cofactor_status s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/!fused);
+      cofactor_status s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/!fused, mask ? mask + done : nullptr);
       if (s != COFACTOR_OK) return s;
     }
   }
   if (a->m > 0) a->cat_check_pending = true;      // flags[1] is looked at by the next snapshot
-  a->dev_rows += (double)rows;
+  if (mask) HIP_TRY(launch_count_mask(mask, rows, a->d_kept, st));
+  else a->dev_rows += (double)rows;
   return COFACTOR_OK;
 }
 
@@ -463,8 +469,14 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
   hipStream_t st = a->ctx->stream;
   out.shape(a->kind, a->n, a->m);
   out.N = a->dev_rows;
+  if (a->dev_dirty) {
+    unsigned long long kept = 0;
+    HIP_TRY(hipMemcpyAsync(&kept, a->d_kept, sizeof(kept), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    out.N += (double)kept;
+  }
   std::vector<double> acc(GRAM_ACC_LEN, 0.0);
-  if (a->n > 0 && a->dev_rows > 0) {
+  if (a->n > 0 && a->dev_dirty) {
     HIP_TRY(hipMemcpyAsync(acc.data(), a->d_acc, sizeof(double) * GRAM_ACC_LEN, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int c = 0; c < a->n; c++) out.lin[c] = acc[gram_lin_pos(c, a->n)];
@@ -476,7 +488,7 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
         for (int k = j; k < a->n; k++) out.quad[q++] = acc[gram_quad_pos(j, k, a->n)];
     }
   }
-  if (!dense_only && a->m > 0 && a->cat_ready && a->dev_rows > 0) {
+  if (!dense_only && a->m > 0 && a->cat_ready && a->dev_dirty) {
     const CatLayout &L = a->L;
     std::vector<unsigned long long> slot(L.n_slots), cnt(L.n_cnt), p(std::max(1, L.n_p));
     std::vector<int32_t> code(L.n_slots);
@@ -651,6 +663,8 @@ cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cof
   a->host.shape(a->kind, a->n, a->m);
   HIP_TRY(hipMalloc((void **)&a->d_acc, sizeof(double) * GRAM_ACC_LEN));
   HIP_TRY(hipMemsetAsync(a->d_acc, 0, sizeof(double) * GRAM_ACC_LEN, ctx->stream));
+  HIP_TRY(hipMalloc((void **)&a->d_kept, sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(a->d_kept, 0, sizeof(unsigned long long), ctx->stream));
   *out = a.release();
   return COFACTOR_OK;
 }
@@ -660,6 +674,7 @@ void cofactor_agg_destroy(cofactor_agg *a) {
   DeviceGuard guard(a->ctx->device);
   (void)hipStreamSynchronize(a->ctx->stream);
   (void)hipFree(a->d_acc);
+  (void)hipFree(a->d_kept);
   if (a->cat_ready) cat_free(a->D);
   if (a->h_num) (void)hipHostFree(a->h_num);
   if (a->h_cat) (void)hipHostFree(a->h_cat);
@@ -675,8 +690,10 @@ cofactor_status cofactor_agg_reset(cofactor_agg *a) {
   a->host.clear();
   a->blob_cache_valid = false;
   a->dev_rows = 0;
+  a->dev_dirty = false;
   a->stage_rows = 0;
   HIP_TRY(hipMemsetAsync(a->d_acc, 0, sizeof(double) * GRAM_ACC_LEN, st));
+  HIP_TRY(hipMemsetAsync(a->d_kept, 0, sizeof(unsigned long long), st));
   if (a->cat_ready) {
     HIP_TRY(hipMemsetAsync(a->D.cnt, 0, sizeof(unsigned long long) * std::max(1, a->L.n_cnt), st));
     HIP_TRY(hipMemsetAsync(a->D.s, 0, sizeof(double) * std::max(1, a->L.n_s), st));
@@ -705,6 +722,30 @@ cofactor_status cofactor_agg_update_device(cofactor_agg *a, const float *const *
   cofactor_status s = stage_flush(a);             // keep row order: staged host rows first
   if (s != COFACTOR_OK) return s;
   return update_device_impl(a, num, cat, rows);
+}
+
+cofactor_status cofactor_agg_update_device_masked(cofactor_agg *a, const float *const *d_num,
+                                                  const int32_t *const *d_cat, const uint8_t *d_mask,
+                                                  uint64_t rows) {
+  if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  if (!d_mask) return cofactor_agg_update_device(a, d_num, d_cat, rows);
+  if ((a->n > 0 && !d_num) || (a->m > 0 && !d_cat)) return fail(COFACTOR_ERR_INVALID, "column array is null");
+  NumCols num{};
+  CatCols cat{};
+  for (int k = 0; k < a->n; k++) {
+    if (!d_num[k] && rows) return fail(COFACTOR_ERR_INVALID, "numeric column pointer is null");
+    if (reinterpret_cast<uintptr_t>(d_num[k]) & 3) return fail(COFACTOR_ERR_INVALID, "numeric column is not 4-byte aligned");
+    num.p[k] = d_num[k];
+  }
+  for (int c = 0; c < a->m; c++) {
+    if (!d_cat[c] && rows) return fail(COFACTOR_ERR_INVALID, "categorical column pointer is null");
+    if (reinterpret_cast<uintptr_t>(d_cat[c]) & 3) return fail(COFACTOR_ERR_INVALID, "categorical column is not 4-byte aligned");
+    cat.p[c] = d_cat[c];
+  }
+  DeviceGuard guard(a->ctx->device);
+  cofactor_status s = stage_flush(a);
+  if (s != COFACTOR_OK) return s;
+  return update_device_impl(a, num, cat, rows, /*allow_optimistic=*/false, d_mask);
 }
 
 cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *num,
@@ -837,8 +878,10 @@ cofactor_status cofactor_agg_import_dense_device(cofactor_agg *a, const double *
     HIP_TRY(hipMemsetAsync(a->D.s, 0, sizeof(double) * std::max(1, a->L.n_s), st));
     HIP_TRY(hipMemsetAsync(a->D.p, 0, sizeof(unsigned long long) * std::max(1, a->L.n_p), st));
   }
+  HIP_TRY(hipMemsetAsync(a->d_kept, 0, sizeof(unsigned long long), st));
   HIP_TRY(hipStreamSynchronize(st));
   a->dev_rows = 0;
+  a->dev_dirty = false;
   a->blob_cache_valid = false;
   a->host = std::move(snap);
   // 2. ... then replace its dense totals by the reduced ones

@@ -187,7 +187,8 @@ __device__ __forceinline__ int lookup_code(SlotPtr slots, CodePtr codes, int cap
 template <bool LDS_TABLES, int KIND, int MT>
 __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num, CatCols cat,
                                                                      uint64_t rows, CatLayout L,
-                                                                     CatDevice D, CatPass P) {
+                                                                     CatDevice D, CatPass P,
+                                                                     const uint8_t *__restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // LDS carve: [dictionary slots (8 B) | sums (8 B) | dictionary codes | counts | pairs (4 B each)]
   const int d_slots = P.dict_lds ? L.n_slots : 0;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
   const bool do_s = KIND == 0 && P.do_s && !(ablate & 2);
   const uint64_t stride = (uint64_t)gridDim.x * CAT_THREADS;
   for (uint64_t r = (uint64_t)blockIdx.x * CAT_THREADS + tid; r < rows; r += stride) {
+    if (mask && mask[r] == 0) continue;                     // masked update: this row is filtered out
     int32_t key[MC];
 #pragma unroll
     for (int c = 0; c < MC; c++)
@@ -296,23 +298,24 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
 
 template <bool LT, int K, int MT>
 hipError_t launch_acc(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
-                      const CatDevice &D, const CatPass &P, int grid, size_t lds, hipStream_t stream) {
+                      const CatDevice &D, const CatPass &P, int grid, size_t lds, const uint8_t *mask,
+                      hipStream_t stream) {
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)cat_accumulate_kernel<LT, K, MT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((cat_accumulate_kernel<LT, K, MT>), dim3(grid), dim3(CAT_THREADS), lds, stream,
-                     num, cat, rows, L, D, P);
+                     num, cat, rows, L, D, P, mask);
   return hipGetLastError();
 }
 
 template <bool LT, int K>
 hipError_t launch_acc_m(int m, const NumCols &num, const CatCols &cat, uint64_t rows,
                         const CatLayout &L, const CatDevice &D, const CatPass &P, int grid, size_t lds,
-                        hipStream_t stream) {
+                        const uint8_t *mask, hipStream_t stream) {
   switch (m) {
-#define CASE(M) case M: return launch_acc<LT, K, M>(num, cat, rows, L, D, P, grid, lds, stream);
+#define CASE(M) case M: return launch_acc<LT, K, M>(num, cat, rows, L, D, P, grid, lds, mask, stream);
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
     CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
 #undef CASE
@@ -374,7 +377,7 @@ hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, con
 hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
                                  const CatLayout &L, const CatDevice &D, const CatPass &P,
                                  bool lds_tables, int grid, hipStream_t stream, hipEvent_t ev0,
-                                 hipEvent_t ev1) {
+                                 hipEvent_t ev1, const uint8_t *mask) {
   if (rows == 0 || L.m == 0) return hipSuccess;
   const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
   if ((uint64_t)grid > need) grid = (int)need;
@@ -382,11 +385,11 @@ hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_
   if (ev0) { hipError_t e = hipEventRecord(ev0, stream); if (e != hipSuccess) return e; }
   hipError_t le;
   if (lds_tables)
-    le = L.kind == 0 ? launch_acc_m<true, 0>(L.m, num, cat, rows, L, D, P, grid, lds, stream)
-                     : launch_acc_m<true, 1>(L.m, num, cat, rows, L, D, P, grid, lds, stream);
+    le = L.kind == 0 ? launch_acc_m<true, 0>(L.m, num, cat, rows, L, D, P, grid, lds, mask, stream)
+                     : launch_acc_m<true, 1>(L.m, num, cat, rows, L, D, P, grid, lds, mask, stream);
   else
-    le = L.kind == 0 ? launch_acc_m<false, 0>(L.m, num, cat, rows, L, D, P, grid, lds, stream)
-                     : launch_acc_m<false, 1>(L.m, num, cat, rows, L, D, P, grid, lds, stream);
+    le = L.kind == 0 ? launch_acc_m<false, 0>(L.m, num, cat, rows, L, D, P, grid, lds, mask, stream)
+                     : launch_acc_m<false, 1>(L.m, num, cat, rows, L, D, P, grid, lds, mask, stream);
   if (le != hipSuccess) return le;
   if (ev1) return hipEventRecord(ev1, stream);
   return hipSuccess;

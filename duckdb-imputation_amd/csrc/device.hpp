@@ -40,9 +40,11 @@ __host__ __device__ inline int gram_lin_pos(int c, int n) {
 // Launches the Gram pass over `rows` rows of n columns and adds the result into acc[GRAM_ACC_LEN]
 // (device doubles).  partials must hold grid * GRAM_ACC_LEN doubles.
 // ev0 / ev1 (optional) are recorded on `stream` right before / after the Gram kernel itself.
+// mask (optional, one byte per row): rows whose byte is 0 contribute nothing.
 hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
                        double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
-                       hipEvent_t ev1 = nullptr);
+                       hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr);
+hipError_t launch_count_mask(const uint8_t *mask, uint64_t rows, unsigned long long *counter, hipStream_t stream);
 
 // adds the per-workgroup images partials[slot][wg] into acc[slot] in a fixed order
 hipError_t launch_gram_fold(const double *partials, int nwg, double *acc, hipStream_t stream);
@@ -88,7 +90,8 @@ hipError_t launch_cat_assign_codes(const CatLayout &L, const CatDevice &D, hipSt
 hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_t rows,
                                  const CatLayout &L, const CatDevice &D, const CatPass &P,
                                  bool lds_tables, int grid, hipStream_t stream,
-                                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                                 const uint8_t *mask = nullptr);
 // re-inserts every (key, code) of the old dictionary into the new one (dictionary growth)
 hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
                              const CatDevice &Dnew, hipStream_t stream);

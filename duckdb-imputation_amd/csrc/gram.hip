@@ -58,7 +58,8 @@ __device__ int g_gram_ablate = 0;   // timing experiments only: 1 = no MFMA loop
 
 template <int N, bool ALIGNED>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64_t rows,
-                                                            double *__restrict__ partials) {
+                                                            double *__restrict__ partials,
+                                                            const uint8_t *__restrict__ mask) {
   constexpr int NB = (N + 3) / 4;
   constexpr int NPAIR = NB * (NB + 1) / 2;
   constexpr int NBC = 4 * NB;                     // data columns incl. zero padding to 4*NB
@@ -86,8 +87,19 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
 
   const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
   float4 pre[LD];
+  unsigned pre_mask = 0x01010101u;                // row mask of this lane's 4 rows, one byte each
   auto fetch = [&](uint64_t t) {
     const uint64_t r0 = t * GRAM_TILE_ROWS;
+    if (mask) {                                   // masked update: rows with a zero byte contribute nothing
+      const uint64_t r = r0 + 4 * lane;
+      if (r + 4 <= rows && (reinterpret_cast<uintptr_t>(mask) & 3) == 0) {
+        pre_mask = *reinterpret_cast<const unsigned *>(mask + r);
+      } else {
+        pre_mask = 0u;
+        for (int e = 0; e < 4; e++)
+          if (r + e < rows) pre_mask |= (unsigned)mask[r + e] << (8 * e);
+      }
+    }
     if (r0 + GRAM_TILE_ROWS <= rows) {            // whole tile in range: straight-line loads
 #pragma unroll
       for (int i = 0; i < LD; i++) {
@@ -106,7 +118,16 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
 #pragma unroll
     for (int i = 0; i < LD; i++) {
       const int col = wave + 4 * i;
-      if (4 * i + 3 < N || col < N) *reinterpret_cast<float4 *>(&tile[col * CS + 4 * lane]) = pre[i];
+      if (4 * i + 3 < N || col < N) {
+        float4 v = pre[i];
+        if (mask) {
+          v.x = (pre_mask & 0x000000FFu) ? v.x : 0.f;
+          v.y = (pre_mask & 0x0000FF00u) ? v.y : 0.f;
+          v.z = (pre_mask & 0x00FF0000u) ? v.z : 0.f;
+          v.w = (pre_mask & 0xFF000000u) ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(&tile[col * CS + 4 * lane]) = v;
+      }
     }
   };
 
@@ -209,13 +230,13 @@ __global__ __launch_bounds__(256) void gram_fold_kernel(const double *__restrict
 
 template <int N>
 hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partials,
-                    hipStream_t stream) {
+                    const uint8_t *mask, hipStream_t stream) {
   bool aligned = true;
   for (int k = 0; k < N; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(cols.p[k]) & 15) == 0);
   if (aligned)
-    hipLaunchKernelGGL((gram_kernel<N, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials);
+    hipLaunchKernelGGL((gram_kernel<N, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
   else
-    hipLaunchKernelGGL((gram_kernel<N, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials);
+    hipLaunchKernelGGL((gram_kernel<N, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
   return hipGetLastError();
 }
 
@@ -226,8 +247,27 @@ hipError_t launch_gram_fold(const double *partials, int nwg, double *acc, hipStr
   return hipGetLastError();
 }
 
+// counter += number of rows whose mask byte is non-zero
+__global__ __launch_bounds__(256) void count_mask_kernel(const uint8_t *__restrict__ mask, uint64_t rows,
+                                                         unsigned long long *__restrict__ counter) {
+  unsigned long long kept = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) kept += mask[r] != 0;
+  for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off, 64);
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, kept);
+}
+
+hipError_t launch_count_mask(const uint8_t *mask, uint64_t rows, unsigned long long *counter, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  uint64_t blocks = (rows + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(count_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mask, rows, counter);
+  return hipGetLastError();
+}
+
 hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
-                       double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                       double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                       const uint8_t *mask) {
   if (rows == 0 || n == 0) return hipSuccess;
 #ifdef COFACTOR_DEV_ABLATE
   {
@@ -242,7 +282,7 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
   hipError_t e = hipErrorInvalidValue;
   if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
   switch (n) {
-#define CASE(N) case N: e = launch_n<N>(cols, rows, grid, partials, stream); break;
+#define CASE(N) case N: e = launch_n<N>(cols, rows, grid, partials, mask, stream); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
     CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
 #undef CASE

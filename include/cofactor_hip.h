@@ -100,6 +100,15 @@ cofactor_status cofactor_agg_reset(cofactor_agg *agg);
 cofactor_status cofactor_agg_update_device(cofactor_agg *agg, const float *const *d_num,
                                            const int32_t *const *d_cat, uint64_t rows);
 
+/* Device form with a row filter: d_mask[i] != 0 keeps row i, 0 drops it (one byte per row, device
+ * memory).  This is the aggregate under a WHERE clause evaluated on the GPU — the MICE drivers'
+ *   SELECT sum_to_triple_n_m(...) FROM t WHERE <col>_IS_NULL IS FALSE
+ * (imputation/algorithms/imputation_base.cpp:21-34, 92-100), where DuckDB would hand update a
+ * selection vector.  N counts kept rows only. */
+cofactor_status cofactor_agg_update_device_masked(cofactor_agg *agg, const float *const *d_num,
+                                                  const int32_t *const *d_cat,
+                                                  const uint8_t *d_mask, uint64_t rows);
+
 /* Host form: what DuckDB hands the aggregate's update callback — one DataChunk (<= 2048 rows in
  * DuckDB, any size here) of host columns in UnifiedVectorFormat.  Column k's value for logical
  * row i is  col[k][ sel && sel[k] ? sel[k][r] : r ]  with  r = row_idx ? row_idx[i] : i

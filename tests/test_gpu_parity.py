@@ -302,6 +302,34 @@ def test_random_shapes_exact(ctx):
         assert got == want, (trial, n, m, nb, keys, rows)
 
 
+@pytest.mark.parametrize("n,m,keys", [(20, 0, 0), (3, 2, 6), (10, 10, 16), (0, 3, 40), (5, 4, 300)])
+def test_masked_update_equals_filtered_rows(ctx, n, m, keys):
+    """cofactor_agg_update_device_masked == the aggregate over the kept rows only (the WHERE
+    <col>_IS_NULL IS FALSE filter of the MICE drivers), N included; mixed with an unmasked update."""
+    import torch
+    rng = np.random.default_rng(500 + n + m)
+    rows = 30_011
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [rng.integers(-1, max(1, keys) - 1, rows).astype(np.int32) for _ in range(m)]
+    mask = (rng.random(rows) < 0.9).astype(np.uint8)
+    mask[:300] = 0                                            # a whole tile filtered out
+    dn = [torch.from_numpy(c).cuda() for c in num]
+    dc = [torch.from_numpy(c).cuda() for c in cat]
+    dm = torch.from_numpy(mask).cuda()
+    torch.cuda.synchronize()
+    agg = ctx.aggregate(n, m)
+    agg.update_device_masked(dn, dc, dm)
+    keep = mask.astype(bool)
+    ref = orc.State(orc.FAITHFUL).update([c[keep] for c in num], [c[keep] for c in cat])
+    assert blob_to_dict(agg.finalize()) == blob_to_dict(ref.finalize())
+    agg.update_device(dn, dc)                                 # then everything, unmasked
+    ref.update(num, cat)
+    assert blob_to_dict(agg.finalize()) == blob_to_dict(ref.finalize())
+    agg.reset()
+    assert blob_to_dict(agg.finalize())["N"] == 0
+    agg.close()
+
+
 def test_nb_aggregate(ctx):
     rng = np.random.default_rng(21)
     rows = 30_000
