@@ -1,0 +1,3 @@
+// Test stand-in (see ../duckdb.hpp).
+#pragma once
+#include "duckdb.hpp"
