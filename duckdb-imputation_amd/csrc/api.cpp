@@ -320,7 +320,8 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
   a->dev_dirty = true;
   cofactor_ctx *ctx = a->ctx;
   hipStream_t st = ctx->stream;
-  bool aligned = rows >= FUSED_TILE_ROWS && !mask;   // the fused kernel wants whole tiles of aligned columns, no row mask
+  bool aligned = rows >= FUSED_TILE_ROWS &&         // the fused kernel wants whole tiles of aligned columns
+                 (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
   for (int k = 0; k < a->n; k++) aligned = aligned && (reinterpret_cast<uintptr_t>(num.p[k]) & 15) == 0;
   for (int c = 0; c < a->m; c++) aligned = aligned && (reinterpret_cast<uintptr_t>(cat.p[c]) & 15) == 0;
   const uint64_t main_rows = rows - rows % FUSED_TILE_ROWS;
@@ -381,7 +382,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       HIP_TRY(hipMemsetAsync(skip, 0, sizeof(unsigned), st));
     }
     HIP_TRY(launch_fused(num, cat, main_rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, skip,
-                         a->d_acc, st, e0, e1));
+                         a->d_acc, st, e0, e1, mask, a->d_kept));
     done = main_rows;
     if (optimistic) {
       HIP_TRY(hipMemcpyAsync(&skipped, skip, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -433,8 +434,11 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
     }
   }
   if (a->m > 0) a->cat_check_pending = true;      // flags[1] is looked at by the next snapshot
-  if (mask) HIP_TRY(launch_count_mask(mask, rows, a->d_kept, st));
-  else a->dev_rows += (double)rows;
+  if (mask) {                                     // the fused kernel counted its own kept rows
+    if (done < rows) HIP_TRY(launch_count_mask(mask + done, rows - done, a->d_kept, st));
+  } else {
+    a->dev_rows += (double)rows;
+  }
   return COFACTOR_OK;
 }
 

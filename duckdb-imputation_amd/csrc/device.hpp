@@ -110,13 +110,15 @@ bool fused_applicable(const CatLayout &L, const int32_t *nkeys, size_t lds_limit
 // workgroups the fused kernel is launched with, and the bytes of per-workgroup pair slabs it needs
 int fused_grid(const CatLayout &L, int cus, int partials_cap_wgs, uint64_t rows);
 size_t fused_slab_bytes(const CatLayout &L, int grid);
+// mask (optional, 4-byte aligned): row filter, kept rows are added to *kept.
 // skip == nullptr: every key must be in the dictionary (else flags[1]).  skip != nullptr
 // (optimistic mode): skip[0] counts and skip[1..] lists the 256-row tiles that met an unknown key and
 // were left out entirely; the caller redoes those tiles after a dictionary pass.
 hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                         const CatDevice &D, int grid, double *partials, unsigned *pair_slabs,
                         unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
-                        hipEvent_t ev1 = nullptr);
+                        hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr,
+                        unsigned long long *kept = nullptr);
 hipError_t launch_gather_tiles(const NumCols &num, const CatCols &cat, int n, int m, const unsigned *list,
                                unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream);
 

@@ -86,6 +86,7 @@ __device__ __noinline__ uint2 lds_lookup4(const unsigned long long *slots, const
 // 0x20 - d has bit 5 set exactly there, with no borrow between the halves.  Plain 32-bit ops
 // (hipcc scalarises 16-bit vector compares into v_cmp/v_cndmask/v_perm chains).
 constexpr unsigned NO_CODE = 16u;
+constexpr unsigned ROW_OFF = 17u;   // code of every column of a row the row filter dropped (matches no i either)
 __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
   unsigned w[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
@@ -108,7 +109,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
                                                               CatLayout L, CatDevice D, FusedCarve cv,
                                                               double *__restrict__ partials,
                                                               unsigned *__restrict__ pair_slabs,
-                                                              unsigned *__restrict__ skip) {
+                                                              unsigned *__restrict__ skip,
+                                                              const uint8_t *__restrict__ mask,
+                                                              unsigned long long *__restrict__ kept) {
   constexpr int NPAIR = NB * (NB + 1) / 2;
   constexpr int NBC = 4 * NB;
   constexpr int MP = (M + 1) / 2;                          // key columns are processed in pairs by the MFMA team
@@ -182,8 +185,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
 
   // ---- loader team: tile fetch (global -> registers) and park (registers -> LDS) ---------------
   // (the launcher only hands this kernel whole tiles of 16-byte aligned columns)
-  auto fetch = [&](uint4 (&pre)[LDX], uint64_t t) {
+  auto fetch = [&](uint4 (&pre)[LDX], unsigned &pre_mask, uint64_t t) {
     const uint64_t r0 = t * TR + 4 * (uint64_t)lane;
+    // row filter of this lane's 4 rows, one byte each (the launcher checked the 4-byte alignment)
+    pre_mask = mask ? *reinterpret_cast<const unsigned *>(mask + r0) : 0x01010101u;
 #pragma unroll
     for (int i = 0; i < LDX; i++) {
       const int vc = tw + 4 * i;                           // wave-uniform virtual column
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       }
     }
   };
-  auto park = [&](const uint4 (&pre)[LDX], int b, unsigned stamp) {
+  auto park = [&](const uint4 (&pre)[LDX], unsigned pre_mask, int b, unsigned stamp) {
     float *xt = xt_of(b);
     unsigned short *pt = pt_of(b);
     unsigned short *codes = codes_of(b);
@@ -203,10 +208,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     for (int i = 0; i < LDX; i++) {
       const int vc = tw + 4 * i;
       if (vc < n) {
-        *reinterpret_cast<uint4 *>(&xt[vc * XCS + 4 * lane]) = pre[i];
+        // filtered rows contribute x = 0 to the Gram and to the per-key sums
+        const unsigned u[4] = {(pre_mask & 0x000000FFu) ? pre[i].x : 0u, (pre_mask & 0x0000FF00u) ? pre[i].y : 0u,
+                               (pre_mask & 0x00FF0000u) ? pre[i].z : 0u, (pre_mask & 0xFF000000u) ? pre[i].w : 0u};
+        *reinterpret_cast<uint4 *>(&xt[vc * XCS + 4 * lane]) = make_uint4(u[0], u[1], u[2], u[3]);
         // x = hi + mid + lo, each a bf16 (exact); inf / nan become 0 here and are added to their
         // own key's cells by the counters (0 x inf would poison every key's cell)
-        const unsigned u[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
         unsigned hi[4], mi[4], lo[4];
         bool nonfinite = false;
 #pragma unroll
@@ -239,6 +246,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
         // know yet is left out as a whole and redone by the host after a dictionary pass
         if (skip && ((packed.x | packed.y) & 0x00100010u))  // some code is NO_CODE
           l_skip[b] = stamp;
+        if (mask) {                                         // filtered rows: code ROW_OFF in every column
+          if (!(pre_mask & 0x000000FFu)) packed.x = (packed.x & 0xFFFF0000u) | ROW_OFF;
+          if (!(pre_mask & 0x0000FF00u)) packed.x = (packed.x & 0x0000FFFFu) | (ROW_OFF << 16);
+          if (!(pre_mask & 0x00FF0000u)) packed.y = (packed.y & 0xFFFF0000u) | ROW_OFF;
+          if (!(pre_mask & 0xFF000000u)) packed.y = (packed.y & 0x0000FFFFu) | (ROW_OFF << 16);
+          *reinterpret_cast<uint2 *>(&codes[c * PTS + 4 * lane]) = packed;
+        }
       }
     }
   };
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     slab_fresh = false;
   };
   // counts and pair counts of tile t (buffer b), one loader thread per row
+  unsigned n_kept = 0;                                     // rows this counter thread counted (masked updates)
   auto count_rows = [&](int b, unsigned stamp) {
     if (ablate & 1) return;
     const unsigned short *codes = codes_of(b);
@@ -266,6 +281,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
 #pragma unroll
     for (int c = 0; c < MC; c++)
       if (c < m) { cd[c] = codes[c * PTS + tt]; known = known && cd[c] < (unsigned)L.kc[c]; }
+    if (cd[0] == ROW_OFF) return;                           // row filtered out by the mask
+    n_kept++;
     if (!known) { D.flags[1] = 1; return; }                 // surfaces as an error at finalize
     // every column has code capacity 16 here (fused_applicable), so pair table q starts at cell
     // 256 q and cell = 256 q + 16 code1 + code2: dword 128 q + 8 code1 + (code2 >> 1), upper half
@@ -395,21 +412,22 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     // its loads are issued (RING tiles ahead of its use) until it is parked
     constexpr int RING = LOAD_RING;
     uint4 pre[RING][LDX];
+    unsigned pmask[RING];
     uint64_t t = blockIdx.x;
     unsigned k = 1;                                         // per-workgroup tile counter = nf stamp
 #pragma unroll
     for (int r = 0; r < RING; r++)
-      if (t + r * G < ntiles) fetch(pre[r], t + r * G);
-    if (t < ntiles) park(pre[0], 0, k);
-    if (t + RING * G < ntiles) fetch(pre[0], t + RING * G);
+      if (t + r * G < ntiles) fetch(pre[r], pmask[r], t + r * G);
+    if (t < ntiles) park(pre[0], pmask[0], 0, k);
+    if (t + RING * G < ntiles) fetch(pre[0], pmask[0], t + RING * G);
     __syncthreads();
     int b = 0;
     while (t < ntiles) {
 #pragma unroll
       for (int r = 0; r < RING; r++) {                      // consuming tile j (j % RING == r)
         const int nx = (r + 1) % RING;
-        if (t + G < ntiles) park(pre[nx], b ^ 1, k + 1);
-        if (t + (RING + 1) * G < ntiles) fetch(pre[nx], t + (RING + 1) * G);
+        if (t + G < ntiles) park(pre[nx], pmask[nx], b ^ 1, k + 1);
+        if (t + (RING + 1) * G < ntiles) fetch(pre[nx], pmask[nx], t + (RING + 1) * G);
         __syncthreads();                                    // buffer b free, buffer b^1 complete
         t += G; b ^= 1; k++;
         if (t >= ntiles) break;
@@ -431,6 +449,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       b ^= 1; k++;
     }
     flush_pairs();
+    if (mask) {                                             // N of a masked update = rows kept
+      unsigned long long kk = n_kept;
+      for (int off = 32; off > 0; off >>= 1) kk += __shfl_down(kk, off, 64);
+      if (lane == 0 && kk) atomicAdd(kept, kk);
+    }
   } else {
     __syncthreads();
     int b = 0, since_g = 0, since_s = 0;
@@ -515,21 +538,23 @@ FusedCarve make_carve(const CatLayout &L, int nb) {
 template <int NB, int NBB, int M>
 hipError_t launch_one(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                       const CatDevice &D, const FusedCarve &cv, int grid, double *partials,
-                      unsigned *slabs, unsigned *skip, hipStream_t stream) {
+                      unsigned *slabs, unsigned *skip, const uint8_t *mask, unsigned long long *kept,
+                      hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute((const void *)fused_kernel<NB, NBB, M>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, cv.total);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((fused_kernel<NB, NBB, M>), dim3(grid), dim3(FUSED_THREADS), cv.total, stream, num,
-                     cat, rows, L, D, cv, partials, slabs, skip);
+                     cat, rows, L, D, cv, partials, slabs, skip, mask, kept);
   return hipGetLastError();
 }
 
 template <int NB, int NBB>
 hipError_t launch_m(int m, const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                      const CatDevice &D, const FusedCarve &cv, int grid, double *partials,
-                     unsigned *slabs, unsigned *skip, hipStream_t stream) {
+                     unsigned *slabs, unsigned *skip, const uint8_t *mask, unsigned long long *kept,
+                     hipStream_t stream) {
   switch (m) {
-#define CASE(M_) case M_: if constexpr (((M_ + 1) / 2) * NBB <= FUSED_MAX_SBLOCKS) return launch_one<NB, NBB, M_>(num, cat, rows, L, D, cv, grid, partials, slabs, skip, stream); else break;
+#define CASE(M_) case M_: if constexpr (((M_ + 1) / 2) * NBB <= FUSED_MAX_SBLOCKS) return launch_one<NB, NBB, M_>(num, cat, rows, L, D, cv, grid, partials, slabs, skip, mask, kept, stream); else break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
     default: break;
@@ -568,13 +593,13 @@ size_t fused_slab_bytes(const CatLayout &L, int grid) {
 hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                         const CatDevice &D, int grid, double *partials, unsigned *pair_slabs,
                         unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0,
-                        hipEvent_t ev1) {
+                        hipEvent_t ev1, const uint8_t *mask, unsigned long long *kept) {
   if (rows == 0) return hipSuccess;
   const int nb = (L.n + 3) / 4, nbb = (3 * L.n + 31) / 32;
   const FusedCarve cv = make_carve(L, nb);
   hipError_t e = hipErrorInvalidValue;
   if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
-#define GO(NB_, NBB_) e = launch_m<NB_, NBB_>(L.m, num, cat, rows, L, D, cv, grid, partials, pair_slabs, skip, stream)
+#define GO(NB_, NBB_) e = launch_m<NB_, NBB_>(L.m, num, cat, rows, L, D, cv, grid, partials, pair_slabs, skip, mask, kept, stream)
   if (nbb == 1) {
     switch (nb) { case 1: GO(1, 1); break; case 2: GO(2, 1); break; case 3: GO(3, 1); break; default: break; }
   } else {
