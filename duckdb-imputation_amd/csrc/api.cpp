@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,9 @@ int next_pow2(int v) {
 }  // namespace
 
 struct cofactor_ctx {
+  // Aggregates of one context share its stream and scratch buffers (partials, pair slabs, skip
+  // list): every entry point that enqueues device work holds this lock for its whole sequence.
+  std::recursive_mutex mu;
   int device = 0;
   hipStream_t stream = nullptr;
   int cus = 0;
@@ -67,6 +71,8 @@ struct cofactor_ctx {
   size_t skip_bytes = 0;
   size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
 };
+
+#define CTX_LOCK(ctxp) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxp)->mu)
 
 struct cofactor_agg {
   cofactor_ctx *ctx = nullptr;
@@ -444,6 +450,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
 
 cofactor_status stage_flush(cofactor_agg *a) {
   if (a->stage_rows == 0) return COFACTOR_OK;
+  CTX_LOCK(a->ctx);
   hipStream_t st = a->ctx->stream;
   const uint64_t cap = a->stage_cap, rows = a->stage_rows;
   NumCols num{};
@@ -467,6 +474,7 @@ cofactor_status stage_flush(cofactor_agg *a) {
 
 // Device tables + host accumulator -> one HostTriple (synchronises).
 cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = false) {
+  CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   cofactor_status s = stage_flush(a);
   if (s != COFACTOR_OK) return s;
@@ -617,6 +625,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
 
 cofactor_status cofactor_ctx_synchronize(cofactor_ctx *ctx) {
   if (!ctx) return fail(COFACTOR_ERR_INVALID, "ctx is null");
+  CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return COFACTOR_OK;
@@ -634,6 +643,7 @@ cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms, ui
                                           double *cat_ms, uint64_t *cat_launches, double *fused_ms,
                                           uint64_t *fused_launches) {
   if (!ctx) return fail(COFACTOR_ERR_INVALID, "ctx is null");
+  CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>> &evs, double *ms, uint64_t *cnt) {
@@ -661,6 +671,7 @@ cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cof
   if (n_num < 0 || n_num > COFACTOR_MAX_NUM || n_cat < 0 || n_cat > COFACTOR_MAX_CAT)
     return fail(COFACTOR_ERR_INVALID, "column counts must be in 0..20");
   if (kind != COFACTOR_TRIPLE && kind != COFACTOR_NB) return fail(COFACTOR_ERR_INVALID, "unknown kind");
+  CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   auto a = std::make_unique<cofactor_agg>();
   a->ctx = ctx; a->n = n_num; a->m = n_cat; a->kind = (int)kind;
@@ -675,6 +686,7 @@ cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cof
 
 void cofactor_agg_destroy(cofactor_agg *a) {
   if (!a) return;
+  CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   (void)hipStreamSynchronize(a->ctx->stream);
   (void)hipFree(a->d_acc);
@@ -689,6 +701,7 @@ void cofactor_agg_destroy(cofactor_agg *a) {
 
 cofactor_status cofactor_agg_reset(cofactor_agg *a) {
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   hipStream_t st = a->ctx->stream;
   a->host.clear();
@@ -709,6 +722,7 @@ cofactor_status cofactor_agg_reset(cofactor_agg *a) {
 cofactor_status cofactor_agg_update_device(cofactor_agg *a, const float *const *d_num,
                                            const int32_t *const *d_cat, uint64_t rows) {
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  CTX_LOCK(a->ctx);
   if ((a->n > 0 && !d_num) || (a->m > 0 && !d_cat)) return fail(COFACTOR_ERR_INVALID, "column array is null");
   NumCols num{};
   CatCols cat{};
@@ -733,6 +747,7 @@ cofactor_status cofactor_agg_update_device_masked(cofactor_agg *a, const float *
                                                   uint64_t rows) {
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
   if (!d_mask) return cofactor_agg_update_device(a, d_num, d_cat, rows);
+  CTX_LOCK(a->ctx);
   if ((a->n > 0 && !d_num) || (a->m > 0 && !d_cat)) return fail(COFACTOR_ERR_INVALID, "column array is null");
   NumCols num{};
   CatCols cat{};
@@ -836,6 +851,7 @@ cofactor_status cofactor_agg_combine(cofactor_agg *dst, cofactor_agg *src) {
 
 cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap, uint64_t *needed) {
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  CTX_LOCK(a->ctx);
   if (!a->blob_cache_valid || a->stage_rows > 0) {
     HostTriple snap;
     cofactor_status s = snapshot(a, snap);
@@ -853,6 +869,7 @@ uint64_t cofactor_dense_len(int n_num, cofactor_kind kind) {
 
 cofactor_status cofactor_agg_export_dense_device(cofactor_agg *a, double *d_out) {
   if (!a || !d_out) return fail(COFACTOR_ERR_INVALID, "null argument");
+  CTX_LOCK(a->ctx);
   HostTriple snap;
   cofactor_status s = snapshot(a, snap, /*dense_only=*/true);
   if (s != COFACTOR_OK) return s;
@@ -868,6 +885,7 @@ cofactor_status cofactor_agg_export_dense_device(cofactor_agg *a, double *d_out)
 
 cofactor_status cofactor_agg_import_dense_device(cofactor_agg *a, const double *d_in) {
   if (!a || !d_in) return fail(COFACTOR_ERR_INVALID, "null argument");
+  CTX_LOCK(a->ctx);
   // 1. pull everything the device holds into the host accumulator ...
   HostTriple snap;
   cofactor_status s = snapshot(a, snap);

@@ -9,7 +9,9 @@
  *
  * Threading contract (mirrors DuckDB's: duckdb_extension/src/triple/sum/sum_state.cpp has no
  * locks): distinct cofactor_agg handles may be used from different threads concurrently; one
- * handle is used by one thread at a time.
+ * handle is used by one thread at a time.  Aggregates of one context share its stream and scratch
+ * buffers; the library serialises their device work with a per-context lock (host-side staging
+ * of different aggregates still runs in parallel).
  *
  * ---------------------------------------------------------------------------------------------
  * Flat triple blob — the host representation of ONE finalised triple: an array of doubles (all

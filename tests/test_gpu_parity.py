@@ -397,6 +397,39 @@ def test_host_chunks_with_selection_vectors_group_by(ctx):
         aggs[g].close()
 
 
+def test_concurrent_states_on_one_context(ctx):
+    """DuckDB calls update from several worker threads at once, each on its own states; all of them
+    share one cofactor_ctx (stream + scratch buffers).  ctypes releases the GIL, so these really
+    overlap inside the library."""
+    import threading
+    rng = np.random.default_rng(123)
+    n, m, rows, workers = 6, 3, 40_000, 6
+    tables = [int_table(np.random.default_rng(1000 + w), rows, n, m, k=5 + 3 * w) for w in range(workers)]
+    aggs = [ctx.aggregate(n, m) for _ in range(workers)]
+    errors = []
+
+    def work(w):
+        try:
+            num, cat = tables[w]
+            for lo in range(0, rows, 2048):                  # DataChunk-sized host updates
+                hi = min(rows, lo + 2048)
+                aggs[w].update_host([c[lo:hi] for c in num], [c[lo:hi] for c in cat])
+            aggs[w].finalize()
+        except Exception as e:                                 # noqa: BLE001
+            errors.append((w, e))
+
+    threads = [threading.Thread(target=work, args=(w,)) for w in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for w in range(workers):
+        want = blob_to_dict(orc.State(orc.FAITHFUL).update(*tables[w]).finalize())
+        assert blob_to_dict(aggs[w].finalize()) == want, w
+        aggs[w].close()
+
+
 def test_fused_equals_unfused_large(ctx):
     """sum_to_triple == sum_triple(to_cofactor(.)) (test_sum.py:40-52) beyond the 5-row table."""
     rng = np.random.default_rng(55)
