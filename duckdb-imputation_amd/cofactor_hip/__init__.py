@@ -117,7 +117,9 @@ class Context:
             lib().cofactor_ctx_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None:          # module globals are already torn down at interpreter exit
+            self.close()
 
     def synchronize(self):
         _check(lib().cofactor_ctx_synchronize(self._h))
@@ -158,7 +160,9 @@ class Aggregate:
             lib().cofactor_agg_destroy(self._h)
         self._h = None
 
-    __del__ = close
+    def __del__(self):
+        if lib is not None:
+            self.close()
 
     def reset(self):
         _check(lib().cofactor_agg_reset(self._h))
