@@ -27,6 +27,9 @@ SYMBOLS = [
     "cofactor_dense_len", "cofactor_agg_export_dense_device", "cofactor_agg_import_dense_device",
     "cofactor_lift_host", "cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub",
     "cofactor_blob_len",
+    "cofactor_linreg_train", "cofactor_lda_train",
+    "cofactor_linreg_predict_device", "cofactor_lda_predict_device",
+    "cofactor_linreg_predict_host", "cofactor_lda_predict_host",
 ]
 
 _lib = None
@@ -81,6 +84,13 @@ def lib():
             getattr(L, f).argtypes = [vp, vp, vp, u64, pu64]
         L.cofactor_blob_len.argtypes = [vp]
         L.cofactor_blob_len.restype = u64
+        i32, f32 = C.c_int32, C.c_float
+        L.cofactor_linreg_train.argtypes = [vp, i32, f32, f32, i32, i32, i32, vp, u64, pu64]
+        L.cofactor_lda_train.argtypes = [vp, i32, f32, i32, vp, u64, pu64]
+        L.cofactor_linreg_predict_device.argtypes = [vp, vp, u64, i32, i32, u64, pp, i32, pp, i32, vp, u64, vp]
+        L.cofactor_lda_predict_device.argtypes = [vp, vp, u64, i32, i32, pp, i32, pp, i32, vp, u64, vp]
+        L.cofactor_linreg_predict_host.argtypes = [vp, vp, u64, i32, i32, u64, pp, i32, pp, i32, u64, vp]
+        L.cofactor_lda_predict_host.argtypes = [vp, vp, u64, i32, i32, pp, i32, pp, i32, u64, vp]
         _lib = L
     return _lib
 
@@ -145,6 +155,72 @@ class Context:
 
     def aggregate(self, n_num, n_cat, kind=TRIPLE):
         return Aggregate(self, n_num, n_cat, kind)
+
+    # ---- per-row predictors over device columns (torch tensors) or host columns (numpy) ----
+    def linreg_predict(self, params, num_cols, cat_cols, out=None, mask=None, noise=False,
+                       normalize=False, seed=0):
+        """linreg_predict(params, noise, normalize, feature columns.., key columns..): device
+        tensors write `out` (float32 device tensor; only rows with mask != 0 when a mask is
+        given), numpy columns return a new float32 array."""
+        prm = np.ascontiguousarray(params, dtype=np.float32)
+        if _on_device(num_cols, cat_cols):
+            rows = out.numel()
+            _check_cols(num_cols, cat_cols, rows, mask)
+            assert str(out.dtype) == "torch.float32" and out.is_cuda and out.is_contiguous()
+            _check(lib().cofactor_linreg_predict_device(
+                self._h, prm.ctypes.data, prm.size, int(noise), int(normalize), seed,
+                _ptr_array([t.data_ptr() for t in num_cols]), len(num_cols),
+                _ptr_array([t.data_ptr() for t in cat_cols]), len(cat_cols),
+                None if mask is None else mask.data_ptr(), rows, out.data_ptr()))
+            return out
+        num = [np.ascontiguousarray(c, dtype=np.float32) for c in num_cols]
+        cat = [np.ascontiguousarray(c, dtype=np.int32) for c in cat_cols]
+        rows = len((num + cat)[0])
+        res = np.empty(rows, dtype=np.float32)
+        _check(lib().cofactor_linreg_predict_host(
+            self._h, prm.ctypes.data, prm.size, int(noise), int(normalize), seed,
+            _ptr_array([c.ctypes.data for c in num]), len(num),
+            _ptr_array([c.ctypes.data for c in cat]), len(cat), rows, res.ctypes.data))
+        return res
+
+    def lda_predict(self, params, num_cols, cat_cols, out=None, mask=None, normalize=False,
+                    emit_label=False):
+        """lda_predict(params, normalize, feature columns.., key columns..) -> class index
+        (the reference's return value) or, with emit_label, the class key."""
+        prm = np.ascontiguousarray(params, dtype=np.float32)
+        if _on_device(num_cols, cat_cols):
+            rows = out.numel()
+            _check_cols(num_cols, cat_cols, rows, mask)
+            assert str(out.dtype) == "torch.int32" and out.is_cuda and out.is_contiguous()
+            _check(lib().cofactor_lda_predict_device(
+                self._h, prm.ctypes.data, prm.size, int(normalize), int(emit_label),
+                _ptr_array([t.data_ptr() for t in num_cols]), len(num_cols),
+                _ptr_array([t.data_ptr() for t in cat_cols]), len(cat_cols),
+                None if mask is None else mask.data_ptr(), rows, out.data_ptr()))
+            return out
+        num = [np.ascontiguousarray(c, dtype=np.float32) for c in num_cols]
+        cat = [np.ascontiguousarray(c, dtype=np.int32) for c in cat_cols]
+        rows = len((num + cat)[0])
+        res = np.empty(rows, dtype=np.int32)
+        _check(lib().cofactor_lda_predict_host(
+            self._h, prm.ctypes.data, prm.size, int(normalize), int(emit_label),
+            _ptr_array([c.ctypes.data for c in num]), len(num),
+            _ptr_array([c.ctypes.data for c in cat]), len(cat), rows, res.ctypes.data))
+        return res
+
+
+def _on_device(num_cols, cat_cols):
+    cols = list(num_cols) + list(cat_cols)
+    return bool(cols) and hasattr(cols[0], "data_ptr")
+
+
+def _check_cols(num_cols, cat_cols, rows, mask):
+    for t, want in [(t, "torch.float32") for t in num_cols] + [(t, "torch.int32") for t in cat_cols]:
+        assert str(t.dtype) == want and t.is_cuda and t.is_contiguous() and t.numel() == rows, \
+            "columns must be 1-D contiguous device tensors of float32 / int32 with one entry per row"
+    if mask is not None:
+        assert str(mask.dtype) == "torch.uint8" and mask.is_cuda and mask.is_contiguous() \
+            and mask.numel() == rows
 
 
 class Aggregate:
@@ -278,6 +354,29 @@ def add(a, b):
 
 def sub(a, b):
     return _binary(lib().cofactor_triple_sub, a, b)
+
+
+def _two_call_f32(fn, *args):
+    need = C.c_uint64(0)
+    _check(fn(*args, None, 0, C.byref(need)))
+    out = np.empty(need.value, dtype=np.float32)
+    _check(fn(*args, out.ctypes.data, out.size, C.byref(need)))
+    return out
+
+
+def linreg_train(triple, label, step_size=0.001, lam=0.0, max_iterations=10000,
+                 compute_variance=False, normalize=False):
+    """linreg_train(triple, label, learning_rate, regularization, max_iterations,
+    include_variance, normalize) -> float32 parameter vector (host; no GPU involved)."""
+    b = np.ascontiguousarray(triple, dtype=np.float64)
+    return _two_call_f32(lib().cofactor_linreg_train, b.ctypes.data, label, step_size, lam,
+                         max_iterations, int(compute_variance), int(normalize))
+
+
+def lda_train(triple, label, shrinkage=0.0, normalize=False):
+    """lda_train(triple, label, shrinkage, normalize) -> float32 parameter vector (host)."""
+    b = np.ascontiguousarray(triple, dtype=np.float64)
+    return _two_call_f32(lib().cofactor_lda_train, b.ctypes.data, label, shrinkage, int(normalize))
 
 
 def blob_len(blob):

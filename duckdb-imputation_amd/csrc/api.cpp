@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "device.hpp"
+#include "ml.hpp"
 #include "triple.hpp"
 
 using namespace cofactor;
@@ -965,5 +966,181 @@ cofactor_status cofactor_triple_sub(const double *a, const double *b, double *ou
 }
 
 uint64_t cofactor_blob_len(const double *blob) { return blob_len(blob); }
+
+// ---- consumers of the triple ----------------------------------------------------------------------
+
+static cofactor_status emit_floats(const std::vector<float> &v, float *out, uint64_t cap,
+                                   uint64_t *needed) {
+  if (needed) *needed = v.size();
+  if (!out) return COFACTOR_OK;
+  if (cap < v.size()) return fail(COFACTOR_ERR_CAPACITY, "output buffer too small");
+  std::memcpy(out, v.data(), v.size() * sizeof(float));
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_linreg_train(const double *triple, int32_t label, float step_size,
+                                      float lambda, int32_t max_iterations,
+                                      int32_t compute_variance, int32_t normalize, float *out,
+                                      uint64_t cap, uint64_t *needed) {
+  if (!triple) return fail(COFACTOR_ERR_INVALID, "null argument");
+  ListTriple t;
+  std::string err;
+  if (!blob_decode(triple, t, err)) return fail(COFACTOR_ERR_INVALID, err);
+  std::vector<float> params;
+  if (!linreg_train(t, label, step_size, lambda, max_iterations, compute_variance != 0,
+                    normalize != 0, params, err))
+    return fail(COFACTOR_ERR_INVALID, err);
+  return emit_floats(params, out, cap, needed);
+}
+
+cofactor_status cofactor_lda_train(const double *triple, int32_t label, float shrinkage,
+                                   int32_t normalize, float *out, uint64_t cap, uint64_t *needed) {
+  if (!triple) return fail(COFACTOR_ERR_INVALID, "null argument");
+  ListTriple t;
+  std::string err;
+  if (!blob_decode(triple, t, err)) return fail(COFACTOR_ERR_INVALID, err);
+  std::vector<float> params;
+  if (!lda_train(t, label, shrinkage, normalize != 0, params, err))
+    return fail(COFACTOR_ERR_INVALID, err);
+  return emit_floats(params, out, cap, needed);
+}
+
+// uploads the model, runs the kernel on the context stream and waits for it (the model buffers
+// are freed on return)
+static cofactor_status predict_device(cofactor_ctx *ctx, const PredictModel &mdl, bool argmax,
+                                      bool emit_label, bool noise, uint64_t seed,
+                                      const float *const *d_num, const int32_t *const *d_cat,
+                                      const uint8_t *d_mask, uint64_t rows, float *out_f,
+                                      int32_t *out_i) {
+  if (mdl.F > COFACTOR_MAX_NUM || mdl.M > COFACTOR_MAX_CAT)
+    return fail(COFACTOR_ERR_UNSUPPORTED, "too many columns");
+  if ((mdl.F && !d_num) || (mdl.M && !d_cat) || (rows && !out_f && !out_i))
+    return fail(COFACTOR_ERR_INVALID, "null argument");
+  NumCols nc{}; CatCols cc{};
+  for (int i = 0; i < mdl.F; i++) {
+    if (!d_num[i] && rows) return fail(COFACTOR_ERR_INVALID, "null numeric column");
+    nc.p[i] = d_num[i];
+  }
+  for (int i = 0; i < mdl.M; i++) {
+    if (!d_cat[i] && rows) return fail(COFACTOR_ERR_INVALID, "null key column");
+    cc.p[i] = d_cat[i];
+  }
+  if (rows == 0) return COFACTOR_OK;
+  CTX_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  const size_t lds_limit = 64 * 1024;
+  int w_in_lds = 0;
+  if (predict_lds_bytes(mdl.F, mdl.M, mdl.C, mdl.KT, lds_limit, &w_in_lds) > lds_limit)
+    return fail(COFACTOR_ERR_UNSUPPORTED, "predict: the key dictionaries of the model exceed the LDS budget");
+  const size_t nk = mdl.kbegin.size() + mdl.keys.size() + mdl.labels.size();
+  int32_t *d_i = nullptr;
+  double *d_w = nullptr;
+  std::vector<int32_t> hi(mdl.kbegin);
+  hi.insert(hi.end(), mdl.keys.begin(), mdl.keys.end());
+  hi.insert(hi.end(), mdl.labels.begin(), mdl.labels.end());
+  HIP_TRY(hipMalloc((void **)&d_i, sizeof(int32_t) * nk));
+  hipError_t e = hipMalloc((void **)&d_w, sizeof(double) * mdl.W.size());
+  if (e == hipSuccess) e = hipMemcpyAsync(d_i, hi.data(), sizeof(int32_t) * nk, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_w, mdl.W.data(), sizeof(double) * mdl.W.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    const int32_t *kb = d_i, *keys = d_i + mdl.kbegin.size(), *labels = keys + mdl.keys.size();
+    e = launch_predict(argmax, nc, cc, mdl.F, mdl.M, mdl.C, mdl.KT, kb, keys, d_w, d_mask, rows,
+                       out_f, out_i, (argmax && emit_label) ? labels : nullptr, noise ? 1 : 0,
+                       mdl.noise_sd, seed, ctx->cus * 8, lds_limit, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_i); (void)hipFree(d_w);
+  if (e != hipSuccess) return fail(COFACTOR_ERR_HIP, hipGetErrorString(e));
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_linreg_predict_device(cofactor_ctx *ctx, const float *params,
+                                               uint64_t n_params, int32_t noise,
+                                               int32_t normalize, uint64_t seed,
+                                               const float *const *d_num, int32_t n_num,
+                                               const int32_t *const *d_cat, int32_t n_cat,
+                                               const uint8_t *d_mask, uint64_t rows, float *d_out) {
+  if (!ctx || !params || n_num < 0 || n_cat < 0) return fail(COFACTOR_ERR_INVALID, "null argument");
+  PredictModel mdl;
+  std::string err;
+  if (!linreg_model(params, n_params, n_num, n_cat, noise != 0, normalize != 0, mdl, err))
+    return fail(COFACTOR_ERR_INVALID, err);
+  return predict_device(ctx, mdl, false, false, noise != 0, seed, d_num, d_cat, d_mask, rows, d_out, nullptr);
+}
+
+cofactor_status cofactor_lda_predict_device(cofactor_ctx *ctx, const float *params,
+                                            uint64_t n_params, int32_t normalize,
+                                            int32_t emit_label, const float *const *d_num,
+                                            int32_t n_num, const int32_t *const *d_cat,
+                                            int32_t n_cat, const uint8_t *d_mask, uint64_t rows,
+                                            int32_t *d_out) {
+  if (!ctx || !params || n_num < 0 || n_cat < 0) return fail(COFACTOR_ERR_INVALID, "null argument");
+  PredictModel mdl;
+  std::string err;
+  if (!lda_model(params, n_params, n_num, n_cat, normalize != 0, mdl, err))
+    return fail(COFACTOR_ERR_INVALID, err);
+  return predict_device(ctx, mdl, true, emit_label != 0, false, 0, d_num, d_cat, d_mask, rows, nullptr, d_out);
+}
+
+// host columns: one packed device buffer [F floats columns | M key columns | out], staged per call
+static cofactor_status predict_host(cofactor_ctx *ctx, const PredictModel &mdl, bool argmax,
+                                    bool emit_label, bool noise, uint64_t seed,
+                                    const float *const *num, const int32_t *const *cat,
+                                    uint64_t rows, void *out) {
+  if ((mdl.F && !num) || (mdl.M && !cat) || (rows && !out)) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (mdl.F > COFACTOR_MAX_NUM || mdl.M > COFACTOR_MAX_CAT) return fail(COFACTOR_ERR_UNSUPPORTED, "too many columns");
+  if (rows == 0) return COFACTOR_OK;
+  CTX_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  const size_t ncol = (size_t)mdl.F + mdl.M + 1;
+  uint32_t *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, ncol * rows * 4));
+  const float *dn[COFACTOR_MAX_NUM]; const int32_t *dc[COFACTOR_MAX_CAT];
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < mdl.F && e == hipSuccess; i++) {
+    dn[i] = reinterpret_cast<const float *>(d + (size_t)i * rows);
+    e = num[i] ? hipMemcpyAsync((void *)dn[i], num[i], rows * 4, hipMemcpyHostToDevice, ctx->stream) : hipErrorInvalidValue;
+  }
+  for (int i = 0; i < mdl.M && e == hipSuccess; i++) {
+    dc[i] = reinterpret_cast<const int32_t *>(d + (size_t)(mdl.F + i) * rows);
+    e = cat[i] ? hipMemcpyAsync((void *)dc[i], cat[i], rows * 4, hipMemcpyHostToDevice, ctx->stream) : hipErrorInvalidValue;
+  }
+  cofactor_status s = COFACTOR_OK;
+  uint32_t *d_out = d + (size_t)(mdl.F + mdl.M) * rows;
+  if (e == hipSuccess)
+    s = predict_device(ctx, mdl, argmax, emit_label, noise, seed, dn, dc, nullptr, rows,
+                       argmax ? nullptr : reinterpret_cast<float *>(d_out),
+                       argmax ? reinterpret_cast<int32_t *>(d_out) : nullptr);
+  if (e == hipSuccess && s == COFACTOR_OK) e = hipMemcpy(out, d_out, rows * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(COFACTOR_ERR_HIP, hipGetErrorString(e));
+  return s;
+}
+
+cofactor_status cofactor_linreg_predict_host(cofactor_ctx *ctx, const float *params,
+                                             uint64_t n_params, int32_t noise, int32_t normalize,
+                                             uint64_t seed, const float *const *num,
+                                             int32_t n_num, const int32_t *const *cat,
+                                             int32_t n_cat, uint64_t rows, float *out) {
+  if (!ctx || !params || n_num < 0 || n_cat < 0) return fail(COFACTOR_ERR_INVALID, "null argument");
+  PredictModel mdl;
+  std::string err;
+  if (!linreg_model(params, n_params, n_num, n_cat, noise != 0, normalize != 0, mdl, err))
+    return fail(COFACTOR_ERR_INVALID, err);
+  return predict_host(ctx, mdl, false, false, noise != 0, seed, num, cat, rows, out);
+}
+
+cofactor_status cofactor_lda_predict_host(cofactor_ctx *ctx, const float *params,
+                                          uint64_t n_params, int32_t normalize,
+                                          int32_t emit_label, const float *const *num,
+                                          int32_t n_num, const int32_t *const *cat, int32_t n_cat,
+                                          uint64_t rows, int32_t *out) {
+  if (!ctx || !params || n_num < 0 || n_cat < 0) return fail(COFACTOR_ERR_INVALID, "null argument");
+  PredictModel mdl;
+  std::string err;
+  if (!lda_model(params, n_params, n_num, n_cat, normalize != 0, mdl, err))
+    return fail(COFACTOR_ERR_INVALID, err);
+  return predict_host(ctx, mdl, true, emit_label != 0, false, 0, num, cat, rows, out);
+}
 
 }  // extern "C"

@@ -122,4 +122,15 @@ hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, c
 hipError_t launch_gather_tiles(const NumCols &num, const CatCols &cat, int n, int m, const unsigned *list,
                                unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream);
 
+// ---- per-row predictors (predict.hip) ------------------------------------------------------------
+// out = W . [1, x_0..x_{F-1}, onehot(keys of the M key columns)] per class; argmax picks the class
+// (labels == nullptr: its index), otherwise class 0's value (+ noise) is written as a float.
+// mask (optional): only rows whose byte is non-zero are written.
+size_t predict_lds_bytes(int F, int M, int C, int KT, size_t lds_limit, int *w_in_lds);
+hipError_t launch_predict(bool argmax, const NumCols &num, const CatCols &cat, int F, int M, int C,
+                          int KT, const int32_t *kbegin, const int32_t *keys, const double *W,
+                          const uint8_t *mask, uint64_t rows, float *out_f, int32_t *out_i,
+                          const int32_t *labels, int noise, double noise_sd,
+                          unsigned long long seed, int grid, size_t lds_limit, hipStream_t stream);
+
 }  // namespace cofactor

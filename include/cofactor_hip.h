@@ -178,6 +178,68 @@ cofactor_status cofactor_triple_sub(const double *a, const double *b, double *ou
 /* Number of doubles in the blob starting at `blob` (walks the lists). */
 uint64_t cofactor_blob_len(const double *blob);
 
+/* ---- consumers of the triple (what one MICE iteration needs) --------------
+ * Training is host fp64 over the p x p cofactor matrix (p = 1 + n + #keys, independent of the
+ * row count) and emits the reference's flat FLOAT[] parameter vector; prediction is a HIP kernel
+ * over device-resident columns.  `out`/`cap`/`needed` count floats, two-call protocol as above. */
+
+/* linreg_train — ML::ridge_linear_regression (duckdb_extension/src/ML/regression.cpp:108-354):
+ * gradient descent with Barzilai-Borwein steps and backtracking on the one-hot sigma matrix
+ * (ML/utils.cpp:176-310).  label = index of the numeric column to predict (0-based).  Output
+ * [m, begin[0..m], keys.., intercept, coefficients of the other numeric columns, of every key,
+ *  (their means if normalize), (residual std if compute_variance)]  (regression.cpp:313-353). */
+cofactor_status cofactor_linreg_train(const double *triple, int32_t label, float step_size,
+                                      float lambda, int32_t max_iterations,
+                                      int32_t compute_variance, int32_t normalize, float *out,
+                                      uint64_t cap, uint64_t *needed);
+
+/* lda_train — lda_train (duckdb_extension/src/ML/lda.cpp:161-416): shrinkage LDA, class means and
+ * pooled within-class covariance from the triple, solved by minimum-norm least squares
+ * (dgelsd there).  label = index of the key column holding the class.  Output
+ * [C, #idx, begin offsets of the other key columns.., their keys.., class keys[C],
+ *  coef[C][p], intercept[C], (means[p] if normalize)]  (lda.cpp:335-386). */
+cofactor_status cofactor_lda_train(const double *triple, int32_t label, float shrinkage,
+                                   int32_t normalize, float *out, uint64_t cap, uint64_t *needed);
+
+/* linreg_predict — ML::linreg_impute (regression.cpp:397-508): per row intercept + coef . x +
+ * the coefficient of each key column's key (a key the model never saw adds 0), optionally plus
+ * N(0, params[last]) noise.  The reference draws the noise from random() seeded off
+ * /dev/urandom; here it is a counter-based generator of (seed, row), so a run is reproducible and
+ * independent of the sharding.  d_num[n_num] are the feature columns in training order WITHOUT
+ * the label, d_cat[n_cat] every key column.  d_mask (optional, one byte per row): only rows with
+ * a non-zero byte are written — `CASE WHEN col_IS_NULL THEN linreg_predict(..) ELSE col END`
+ * (imputation/algorithms/imputation_base.cpp:137) as an in-place column update. */
+cofactor_status cofactor_linreg_predict_device(cofactor_ctx *ctx, const float *params,
+                                               uint64_t n_params, int32_t noise,
+                                               int32_t normalize, uint64_t seed,
+                                               const float *const *d_num, int32_t n_num,
+                                               const int32_t *const *d_cat, int32_t n_cat,
+                                               const uint8_t *d_mask, uint64_t rows, float *d_out);
+
+/* lda_predict — LDA_impute (lda.cpp:421-590): argmax over classes of intercept + coef . [x,
+ * onehot].  d_cat[n_cat] are the key columns in training order WITHOUT the label.  The reference
+ * returns the class INDEX (lda.cpp:560); emit_label != 0 writes the class key instead, which is
+ * what an in-place imputation needs.  d_mask as above. */
+cofactor_status cofactor_lda_predict_device(cofactor_ctx *ctx, const float *params,
+                                            uint64_t n_params, int32_t normalize,
+                                            int32_t emit_label, const float *const *d_num,
+                                            int32_t n_num, const int32_t *const *d_cat,
+                                            int32_t n_cat, const uint8_t *d_mask, uint64_t rows,
+                                            int32_t *d_out);
+
+/* The same two over host columns (a DuckDB DataChunk): staged to the device, predicted there,
+ * copied back; every row is written. */
+cofactor_status cofactor_linreg_predict_host(cofactor_ctx *ctx, const float *params,
+                                             uint64_t n_params, int32_t noise, int32_t normalize,
+                                             uint64_t seed, const float *const *num,
+                                             int32_t n_num, const int32_t *const *cat,
+                                             int32_t n_cat, uint64_t rows, float *out);
+cofactor_status cofactor_lda_predict_host(cofactor_ctx *ctx, const float *params,
+                                          uint64_t n_params, int32_t normalize,
+                                          int32_t emit_label, const float *const *num,
+                                          int32_t n_num, const int32_t *const *cat, int32_t n_cat,
+                                          uint64_t rows, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+"""One MICE run on device-resident columns (SURVEY.md §3.4, config C5's shape at test size):
+masked aggregate -> train -> predict in place, per incomplete column.  There is no golden for
+this in the reference (its driver needs a DuckDB connection); the checks are the ones the
+algorithm guarantees: present values are never touched, missing ones are filled, and the
+model-based fill beats the AVG / MODE fill it starts from."""
+import numpy as np
+import pytest
+
+import cofactor_hip
+from cofactor_hip import mice
+from oracle import ml_oracle, oracle
+from triple_fmt import blob_to_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(rows, seed=3):
+    import torch
+    rng = np.random.default_rng(seed)
+    x1 = rng.normal(size=rows).astype(np.float32)
+    x2 = rng.normal(size=rows).astype(np.float32)
+    k1 = rng.integers(0, 4, rows).astype(np.int32) * 3 + 5          # keys 5, 8, 11, 14
+    k0_true = ((x1 + 0.5 * x2 + 0.3 * rng.normal(size=rows)) > 0).astype(np.int32) + (k1 > 8) * 2
+    k0_true = (k0_true * 10 + 1).astype(np.int32)                  # keys 1, 11, 21, 31
+    x0_true = (2.0 * x1 - x2 + 0.7 * (k1 == 8) + 0.1 * rng.normal(size=rows)).astype(np.float32)
+    x0_null = rng.random(rows) < 0.1
+    k0_null = rng.random(rows) < 0.1
+    x0 = np.where(x0_null, np.float32(-999), x0_true).astype(np.float32)   # what a NULL slot holds
+    k0 = np.where(k0_null, np.int32(-999), k0_true).astype(np.int32)      # must never be read
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t = mice.MiceTable({"x0": dev(x0), "x1": dev(x1), "x2": dev(x2)}, {"k0": dev(k0), "k1": dev(k1)},
+                       {"x0": dev(x0_null.astype(np.uint8))}, {"k0": dev(k0_null.astype(np.uint8))})
+    return t, dict(x0=x0_true, k0=k0_true, x0_null=x0_null, k0_null=k0_null, x1=x1, x2=x2, k1=k1)
+
+
+def test_init_baseline_fills_avg_and_mode():
+    t, truth = _table(50_000)
+    ctx = cofactor_hip.Context(0)
+    mice.init_baseline(ctx, t)
+    x0, k0 = t.num["x0"].cpu().numpy(), t.cat["k0"].cpu().numpy()
+    present = ~truth["x0_null"]
+    assert np.array_equal(x0[present], truth["x0"][present])
+    assert np.allclose(x0[~present], truth["x0"][present].astype(np.float64).mean(), rtol=1e-5)
+    kp = ~truth["k0_null"]
+    assert np.array_equal(k0[kp], truth["k0"][kp])
+    vals, cnt = np.unique(truth["k0"][kp], return_counts=True)
+    assert np.all(k0[~kp] == vals[np.argmax(cnt)])
+    ctx.close()
+
+
+def test_mice_iteration_improves_on_the_baseline_fill():
+    t, truth = _table(200_000)
+    ctx = cofactor_hip.Context(0)
+    mice.init_baseline(ctx, t)
+    xn, kn = truth["x0_null"], truth["k0_null"]
+    base_rmse = float(np.sqrt(np.mean((t.num["x0"].cpu().numpy()[xn] - truth["x0"][xn]) ** 2)))
+    base_acc = float(np.mean(t.cat["k0"].cpu().numpy()[kn] == truth["k0"][kn]))
+    log = {}
+    models = mice.run_mice(ctx, t, iterations=2, seed=11, timings=log, skip_init=True)
+    x0, k0 = t.num["x0"].cpu().numpy(), t.cat["k0"].cpu().numpy()
+    assert np.array_equal(x0[~xn], truth["x0"][~xn]) and np.array_equal(k0[~kn], truth["k0"][~kn])
+    assert set(np.unique(k0)) <= {1, 11, 21, 31}
+    rmse = float(np.sqrt(np.mean((x0[xn] - truth["x0"][xn]) ** 2)))
+    acc = float(np.mean(k0[kn] == truth["k0"][kn]))
+    assert rmse < 0.5 * base_rmse, (rmse, base_rmse)
+    assert acc > base_acc + 0.3, (acc, base_acc)
+    assert set(models) == {"x0", "k0"} and all(v > 0 for v in log.values())
+
+    # the last linear model is the one the CPU restatement trains from the CPU triple of the same
+    # (now complete) present rows, and the stochastic fill is prediction + N(0, residual std)
+    keep = ~xn
+    cols = lambda names, src: [src[c][keep] for c in names]
+    final = {"x0": x0, "x1": truth["x1"], "x2": truth["x2"], "k0": k0, "k1": truth["k1"]}
+    blob = oracle.State(oracle.WIDE).update(cols(["x0", "x1", "x2"], final), cols(["k0", "k1"], final)).finalize()
+    want = ml_oracle.linreg_train(blob_to_dict(blob), 0, 0.001, 0.0, 10000, True, False)
+    assert np.allclose(models["x0"], want, rtol=2e-3, atol=2e-3)
+    mean_pred = ml_oracle.linreg_predict(models["x0"], False, False,
+                                         [truth["x1"][xn][:2000], truth["x2"][xn][:2000]],
+                                         [k0[xn][:2000], truth["k1"][xn][:2000]])
+    z = (x0[xn][:2000] - mean_pred) / float(models["x0"][-1])
+    assert abs(z.mean()) < 0.1 and abs(z.std() - 1) < 0.1
+    ctx.close()
