@@ -199,29 +199,38 @@ void solve_symmetric_min_norm(std::vector<double> &A, size_t p, std::vector<doub
 
 namespace {
 
-// 1/N * Sigma * theta with the label's entry forced to 0 (compute_gradient, regression.cpp:27-46)
-void gradient(size_t p, size_t label, const std::vector<double> &s, const std::vector<double> &th,
-              std::vector<double> &g) {
-  if (s[0] == 0.0) return;
+// v = Sigma * theta: the one product both the gradient and the objective need (the reference
+// forms it twice per iteration, compute_gradient regression.cpp:27-46 and compute_error :48-77).
+// Four partial sums per row so the loop vectorises.
+void sigma_times(size_t p, const std::vector<double> &s, const std::vector<double> &th,
+                 std::vector<double> &v) {
   for (size_t i = 0; i < p; i++) {
-    double v = 0;
-    for (size_t j = 0; j < p; j++) v += s[i * p + j] * th[j];
-    g[i] = v / s[0];
+    const double *row = &s[i * p];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    size_t j = 0;
+    for (; j + 4 <= p; j += 4) {
+      a0 += row[j] * th[j]; a1 += row[j + 1] * th[j + 1];
+      a2 += row[j + 2] * th[j + 2]; a3 += row[j + 3] * th[j + 3];
+    }
+    for (; j < p; j++) a0 += row[j] * th[j];
+    v[i] = (a0 + a1) + (a2 + a3);
   }
+}
+
+// 1/N * Sigma * theta with the label's entry forced to 0
+void gradient(size_t p, size_t label, double N, const std::vector<double> &v, std::vector<double> &g) {
+  if (N == 0.0) return;
+  for (size_t i = 0; i < p; i++) g[i] = v[i] / N;
   g[label] = 0;
 }
 
-// (theta^T Sigma theta / N + lambda (|theta_1..|^2 - 1)) / 2  (compute_error, regression.cpp:48-77)
-double objective(size_t p, const std::vector<double> &s, const std::vector<double> &th,
+// (theta^T Sigma theta / N + lambda (|theta_1..|^2 - 1)) / 2
+double objective(size_t p, double N, const std::vector<double> &v, const std::vector<double> &th,
                  double lambda) {
-  if (s[0] == 0.0) return 0;
+  if (N == 0.0) return 0;
   double e = 0;
-  for (size_t i = 0; i < p; i++) {
-    double v = 0;
-    for (size_t j = 0; j < p; j++) v += s[i * p + j] * th[j];
-    e += th[i] * v;
-  }
-  e /= s[0];
+  for (size_t i = 0; i < p; i++) e += th[i] * v[i];
+  e /= N;
   double nrm = 0;
   for (size_t i = 1; i < p; i++) nrm += th[i] * th[i];
   nrm -= 1;
@@ -256,10 +265,12 @@ bool linreg_train(const ListTriple &t, int label0, float step_size, float lambda
   std::vector<double> mean, sd;
   if (normalize) standardize(sigma, p, mean, sd);
 
-  std::vector<double> g(p, 0), pg(p, 0), th(p, 0), pth(p, 0), upd(p, 0);
+  std::vector<double> g(p, 0), pg(p, 0), th(p, 0), pth(p, 0), upd(p, 0), sv(p, 0);
   const size_t label = (size_t)label0 + 1;  // slot 0 is the intercept
+  const double N = sigma[0];
   th[label] = pth[label] = -1;
-  gradient(p, label, sigma, th, g);
+  sigma_times(p, sigma, th, sv);
+  gradient(p, label, N, sv, g);
   double gnorm = g[0] * g[0];
   for (size_t i = 1; i < p; i++) {
     const double u = g[i] + lambda * th[i];
@@ -267,7 +278,7 @@ bool linreg_train(const ListTriple &t, int label0, float step_size, float lambda
   }
   gnorm -= (double)lambda * lambda;
   const double first_gnorm = std::sqrt(gnorm);
-  double prev_err = objective(p, sigma, th, lambda);
+  double prev_err = objective(p, N, sv, th, lambda);
 
   // the reference keeps the step in a float (regression.cpp:115); so do we, the trajectory of the
   // descent depends on it
@@ -289,7 +300,8 @@ bool linreg_train(const ListTriple &t, int label0, float step_size, float lambda
     th[label] = -1;
     gnorm -= (double)lambda * lambda;
     dnorm = step * std::sqrt(dnorm);
-    double e = objective(p, sigma, th, lambda);
+    sigma_times(p, sigma, th, sv);
+    double e = objective(p, N, sv, th, lambda);
     int back = 0;
     while (e > prev_err - (step / 2) * gnorm && back < 500) {  // backtracking line search
       step /= 2;
@@ -301,12 +313,13 @@ bool linreg_train(const ListTriple &t, int label0, float step_size, float lambda
       }
       dnorm = std::sqrt(dnorm);
       th[label] = -1;
-      e = objective(p, sigma, th, lambda);
+      sigma_times(p, sigma, th, sv);
+      e = objective(p, N, sv, th, lambda);
       back++;
     }
     gnorm = std::sqrt(gnorm);
     if (dnorm < 1e-20 || gnorm / (first_gnorm + 0.001) < 1e-8) break;
-    gradient(p, label, sigma, th, g);
+    gradient(p, label, N, sv, g);   // sv is Sigma * theta of the accepted point
     step = (float)bb_step(step, p, th, pth, g, pg);
     prev_err = e;
     it++;
@@ -315,11 +328,8 @@ bool linreg_train(const ListTriple &t, int label0, float step_size, float lambda
   double variance = 0;
   if (compute_variance) {  // theta^T Sigma theta / N with theta[label] = -1: the residual variance
     th[label] = -1;
-    for (size_t i = 0; i < p; i++) {
-      double v = 0;
-      for (size_t j = 0; j < p; j++) v += sigma[i * p + j] * th[j];
-      variance += th[i] * v;
-    }
+    sigma_times(p, sigma, th, sv);
+    for (size_t i = 0; i < p; i++) variance += th[i] * sv[i];
     variance /= t.N;
   }
   if (normalize) {
