@@ -8,6 +8,10 @@
 //   sum_triple(triple), sum_nb_agg(triple)                          -> update_triples
 //   to_cofactor(cols...), to_nb_agg(cols...)                        -> cofactor_lift_host
 //   multiply_triple(a, b), multiply_nb_agg(a, b)                    -> cofactor_triple_multiply
+//   linreg_train(triple, label, step, lambda, iters, variance, normalize)  -> cofactor_linreg_train
+//   lda_train(triple, label, shrinkage, normalize)                  -> cofactor_lda_train
+//   linreg_predict(params, noise, normalize, cols...)               -> cofactor_linreg_predict_host
+//   lda_predict(params, normalize, cols...)                         -> cofactor_lda_predict_host
 //
 // This translation unit needs DuckDB's headers (<duckdb.hpp>, v0.9.2 @ 3c695d7b) and is built
 // inside a DuckDB checkout exactly like the reference (see ../CMakeLists.txt); it is NOT compiled
@@ -17,7 +21,9 @@
 
 #include "duckdb_imputation_extension.hpp"
 
+#include <atomic>
 #include <mutex>
+#include <random>
 #include <unordered_map>
 
 #include "cofactor_hip.h"
@@ -392,13 +398,141 @@ static void LoadRing(DatabaseInstance &instance) {
     }
 }
 
+// ---- consumers of the triple (reference: load_ml, duckdb_imputation_extension.cpp:182-249) ---------
+static unique_ptr<FunctionData> FloatListBind(ClientContext &, ScalarFunction &function,
+                                              vector<unique_ptr<Expression>> &) {
+  function.return_type = LogicalType::LIST(LogicalType::FLOAT);      // regression.cpp:356-362, lda.cpp:154-159
+  return make_uniq<VariableReturnBindData>(function.return_type);
+}
+
+template <class T>
+static T ConstArg(DataChunk &args, idx_t col, const char *fn) {     // args.data[i].GetValue(0).GetValue<T>()
+  if (col >= args.ColumnCount()) throw InvalidInputException("%s: too few arguments", fn);
+  return args.data[col].GetValue(0).GetValue<T>();
+}
+
+// one parameter vector as a constant LIST(FLOAT) (regression.cpp:288-312)
+static void EmitFloatList(Vector &result, const std::vector<float> &v) {
+  result.SetVectorType(VectorType::CONSTANT_VECTOR);
+  ListVector::Reserve(result, v.size());
+  ListVector::SetListSize(result, v.size());
+  auto out = FlatVector::GetData<float>(ListVector::GetEntry(result));
+  for (idx_t i = 0; i < v.size(); i++) out[i] = v[i];
+  auto meta = ListVector::GetData(result);
+  meta[0].offset = 0;
+  meta[0].length = v.size();
+}
+
+// linreg_train(triple, label, step_size, lambda, max_iterations, compute_variance, normalize)
+static void LinregTrain(DataChunk &args, ExpressionState &, Vector &result) {
+  RecursiveFlatten(args.data[0], args.size());
+  std::vector<double> blob;
+  RowToBlob(args.data[0], 0, false, blob);
+  const int label = ConstArg<int32_t>(args, 1, "linreg_train");
+  const float step = ConstArg<float>(args, 2, "linreg_train"), lambda = ConstArg<float>(args, 3, "linreg_train");
+  const int iters = ConstArg<int32_t>(args, 4, "linreg_train");
+  const bool variance = ConstArg<bool>(args, 5, "linreg_train"), normalize = ConstArg<bool>(args, 6, "linreg_train");
+  uint64_t need = 0;
+  Check(cofactor_linreg_train(blob.data(), label, step, lambda, iters, variance, normalize, nullptr, 0, &need));
+  std::vector<float> params(need);
+  Check(cofactor_linreg_train(blob.data(), label, step, lambda, iters, variance, normalize, params.data(), need, &need));
+  EmitFloatList(result, params);
+}
+
+// lda_train(triple, label, shrinkage, normalize)
+static void LdaTrain(DataChunk &args, ExpressionState &, Vector &result) {
+  RecursiveFlatten(args.data[0], args.size());
+  std::vector<double> blob;
+  RowToBlob(args.data[0], 0, false, blob);
+  const int label = ConstArg<int32_t>(args, 1, "lda_train");
+  const float shrinkage = ConstArg<float>(args, 2, "lda_train");
+  const bool normalize = ConstArg<bool>(args, 3, "lda_train");
+  uint64_t need = 0;
+  Check(cofactor_lda_train(blob.data(), label, shrinkage, normalize, nullptr, 0, &need));
+  std::vector<float> params(need);
+  Check(cofactor_lda_train(blob.data(), label, shrinkage, normalize, params.data(), need, &need));
+  EmitFloatList(result, params);
+}
+
+// the FLOAT[] parameter argument (a constant list) and the feature columns after `first`
+struct PredictArgs {
+  std::vector<float> params;
+  vector<const float *> num;
+  vector<const int32_t *> cat;
+  PredictArgs(DataChunk &args, idx_t first) {
+    const idx_t rows = args.size();
+    RecursiveFlatten(args.data[0], rows);
+    auto meta = ListVector::GetData(args.data[0]);
+    auto child = FlatVector::GetData<float>(ListVector::GetEntry(args.data[0]));
+    params.assign(child + meta[0].offset, child + meta[0].offset + meta[0].length);
+    for (idx_t j = first; j < args.ColumnCount(); j++) {
+      args.data[j].Flatten(rows);
+      if (args.data[j].GetType() == LogicalType::FLOAT) num.push_back(FlatVector::GetData<float>(args.data[j]));
+      else if (args.data[j].GetType() == LogicalType::INTEGER) cat.push_back(FlatVector::GetData<int32_t>(args.data[j]));
+      else throw InvalidInputException("predict: feature columns must be FLOAT or INTEGER");
+    }
+  }
+};
+
+static uint64_t NoiseSeed() {     // the reference seeds random() off /dev/urandom once (regression.cpp:377-395)
+  static std::atomic<uint64_t> next{std::random_device{}() * 0x9E3779B97F4A7C15ull};
+  return next.fetch_add(0x632BE59BD9B4E019ull);
+}
+
+// linreg_predict(params, noise, normalize, feature columns...)
+static void LinregPredict(DataChunk &args, ExpressionState &, Vector &result) {
+  const bool noise = ConstArg<bool>(args, 1, "linreg_predict"), normalize = ConstArg<bool>(args, 2, "linreg_predict");
+  PredictArgs in(args, 3);
+  result.SetVectorType(VectorType::FLAT_VECTOR);
+  Check(cofactor_linreg_predict_host(Context(), in.params.data(), in.params.size(), noise, normalize,
+                                     noise ? NoiseSeed() : 0, in.num.data(), (int32_t)in.num.size(), in.cat.data(),
+                                     (int32_t)in.cat.size(), args.size(), FlatVector::GetData<float>(result)));
+}
+
+// lda_predict(params, normalize, feature columns...) -> class index (lda.cpp:560)
+static void LdaPredict(DataChunk &args, ExpressionState &, Vector &result) {
+  const bool normalize = ConstArg<bool>(args, 1, "lda_predict");
+  PredictArgs in(args, 2);
+  result.SetVectorType(VectorType::FLAT_VECTOR);
+  Check(cofactor_lda_predict_host(Context(), in.params.data(), in.params.size(), normalize, /*emit_label=*/0,
+                                  in.num.data(), (int32_t)in.num.size(), in.cat.data(), (int32_t)in.cat.size(),
+                                  args.size(), FlatVector::GetData<int32_t>(result)));
+}
+
+static unique_ptr<FunctionData> FloatBind(ClientContext &, ScalarFunction &function, vector<unique_ptr<Expression>> &) {
+  function.return_type = LogicalType::FLOAT;                          // regression.cpp:365-374
+  function.varargs = LogicalType::ANY;
+  return make_uniq<VariableReturnBindData>(function.return_type);
+}
+static unique_ptr<FunctionData> IntegerBind(ClientContext &, ScalarFunction &function, vector<unique_ptr<Expression>> &) {
+  function.return_type = LogicalType::INTEGER;                        // lda.cpp:593-601
+  function.varargs = LogicalType::ANY;
+  return make_uniq<VariableReturnBindData>(function.return_type);
+}
+
+static void LoadML(DatabaseInstance &instance) {
+  auto reg = [&](const char *name, LogicalTypeId ret, scalar_function_t fn, bind_scalar_function_t bind) {
+    ScalarFunction f(name, {LogicalType::ANY}, ret, fn, bind);
+    f.varargs = LogicalType::ANY;
+    f.null_handling = FunctionNullHandling::SPECIAL_HANDLING;
+    f.serialize = VariableReturnBindData::Serialize;
+    f.deserialize = VariableReturnBindData::Deserialize;
+    ExtensionUtil::RegisterFunction(instance, f);
+  };
+  reg("linreg_train", LogicalTypeId::LIST, LinregTrain, FloatListBind);
+  reg("lda_train", LogicalTypeId::LIST, LdaTrain, FloatListBind);
+  reg("linreg_predict", LogicalTypeId::INTEGER, LinregPredict, FloatBind);
+  reg("lda_predict", LogicalTypeId::INTEGER, LdaPredict, IntegerBind);
+}
+
 }  // namespace cofactor_glue
 
 void DuckdbImputationExtension::Load(DuckDB &db) {
   cofactor_glue::LoadRing<false>(*db.instance);
   cofactor_glue::LoadRing<true>(*db.instance);
-  // The ML functions (lda_*/linreg_*/qda_*/nb_*) consume finalised triples and are outside this
-  // library's hot path; a build that wants them links the reference's ML/*.cpp.
+  cofactor_glue::LoadML(*db.instance);
+  // qda_* / nb_* consume finalised triples too and are outside this library's scope (DESIGN.md
+  // §8); a build that wants them links the reference's ML/qda.cpp and ML/naive_bayes.cpp.
 }
 std::string DuckdbImputationExtension::Name() { return "duckdb_imputation"; }
 

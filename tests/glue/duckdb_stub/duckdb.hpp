@@ -59,7 +59,7 @@ struct InvalidInputException : Exception {
   template <class... A> InvalidInputException(const char *fmt, A... a) : Exception(IOException::Fmt(fmt, a...)) {}
 };
 
-enum class LogicalTypeId : uint8_t { INVALID, ANY, INTEGER, FLOAT, DOUBLE, VARCHAR, LIST, STRUCT };
+enum class LogicalTypeId : uint8_t { INVALID, ANY, BOOLEAN, INTEGER, FLOAT, DOUBLE, VARCHAR, LIST, STRUCT };
 enum class PhysicalType : uint8_t { INVALID, INT32, FLOAT, DOUBLE, VARCHAR, LIST, STRUCT };
 enum class VectorType : uint8_t { FLAT_VECTOR, CONSTANT_VECTOR, DICTIONARY_VECTOR };
 enum class FunctionNullHandling : uint8_t { DEFAULT_NULL_HANDLING, SPECIAL_HANDLING };
@@ -93,6 +93,7 @@ struct LogicalType {
     t.children = std::make_shared<child_list_t<LogicalType>>(std::move(fields));
     return t;
   }
+  static constexpr LogicalTypeId BOOLEAN = LogicalTypeId::BOOLEAN;
   static constexpr LogicalTypeId INTEGER = LogicalTypeId::INTEGER;
   static constexpr LogicalTypeId FLOAT = LogicalTypeId::FLOAT;
   static constexpr LogicalTypeId DOUBLE = LogicalTypeId::DOUBLE;
@@ -106,6 +107,7 @@ struct StructType { static const child_list_t<LogicalType> &GetChildTypes(const 
 
 static inline idx_t TypeSize(const LogicalType &t) {
   switch (t.id()) {
+  case LogicalTypeId::BOOLEAN: return 1;
   case LogicalTypeId::INTEGER: case LogicalTypeId::FLOAT: return 4;
   case LogicalTypeId::DOUBLE: return 8;
   case LogicalTypeId::LIST: return sizeof(list_entry_t);
@@ -129,6 +131,15 @@ struct UnifiedVectorFormat {
   template <class T> static const T *GetData(const UnifiedVectorFormat &f) { return reinterpret_cast<const T *>(f.data); }
 };
 
+// what Vector::GetValue(i).GetValue<T>() needs: a scalar that casts
+class Value {
+public:
+  explicit Value(double v) : d(v) {}
+  template <class T> T GetValue() const { return static_cast<T>(d); }
+private:
+  double d;
+};
+
 class Vector {
 public:
   explicit Vector(LogicalType t, idx_t capacity = 2048) : type(std::move(t)) { Init(capacity); }
@@ -150,6 +161,16 @@ public:
     auto nb = std::make_shared<std::vector<data_t>>(std::max<idx_t>(count, 1) * w);
     for (idx_t i = 0; i < count; i++) std::memcpy(nb->data() + i * w, buffer->data() + (*dict)[i] * w, w);
     buffer = nb; dict.reset(); vtype = VectorType::FLAT_VECTOR;
+  }
+  Value GetValue(idx_t i) const {
+    const idx_t r = dict ? (*dict)[i] : i;
+    switch (type.id()) {
+    case LogicalTypeId::BOOLEAN: return Value(buffer->data()[r] != 0);
+    case LogicalTypeId::INTEGER: return Value(reinterpret_cast<const int32_t *>(buffer->data())[r]);
+    case LogicalTypeId::FLOAT: return Value(reinterpret_cast<const float *>(buffer->data())[r]);
+    case LogicalTypeId::DOUBLE: return Value(reinterpret_cast<const double *>(buffer->data())[r]);
+    default: throw InvalidInputException("stub: GetValue on a nested vector");
+    }
   }
   // internals (public for the helper structs below)
   LogicalType type;

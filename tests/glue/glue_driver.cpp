@@ -2,9 +2,11 @@
 // through the callback sequence DuckDB's executor uses, against the test stand-in of the DuckDB
 // API in duckdb_stub/ (the image has no DuckDB).  Prints one JSON document; tests/test_glue.py
 // compares it with the reference's golden literals.  Needs a GPU (update goes to the HIP kernels).
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <iomanip>
 #include <sstream>
 #include <string>
 
@@ -155,7 +157,8 @@ int main() {
                            "sum_to_nb_agg_20_20", "sum_to_triple_0_0"};
     for (size_t i = 0; i < sizeof(names) / sizeof(*names); i++)
       out << (i ? "," : "") << "\"" << names[i] << "\":" << (db.aggregates.count(names[i]) ? "true" : "false");
-    const char *snames[] = {"to_cofactor", "to_nb_agg", "multiply_triple", "multiply_nb_agg"};
+    const char *snames[] = {"to_cofactor", "to_nb_agg", "multiply_triple", "multiply_nb_agg",
+                            "linreg_train", "linreg_predict", "lda_train", "lda_predict"};
     for (auto n : snames) out << ",\"" << n << "\":" << (db.scalars.count(n) ? "true" : "false");
     out << "}";
 
@@ -229,6 +232,68 @@ int main() {
         mul.function(chunk, es, prod);
         out << ",\"" << pfx << "multiply\":" << Rows(prod, 1);
       }
+    }
+    {  // the consumers: linreg_train / linreg_predict / lda_train / lda_predict on the 5-row table
+      auto constant = [](LogicalTypeId t, double v) {
+        Vector c(t, 1);
+        c.SetVectorType(VectorType::CONSTANT_VECTOR);
+        if (t == LogicalTypeId::BOOLEAN) FlatVector::GetData<uint8_t>(c)[0] = v != 0;
+        else if (t == LogicalTypeId::INTEGER) FlatVector::GetData<int32_t>(c)[0] = (int32_t)v;
+        else FlatVector::GetData<float>(c)[0] = (float)v;
+        return c;
+      };
+      auto call = [&](const char *name, DataChunk &chunk, idx_t rows) {
+        auto &fn = db.scalars.at(name);
+        ClientContext ctx; ExpressionState es;
+        vector<unique_ptr<Expression>> args;
+        auto bd = fn.bind(ctx, fn, args);
+        Vector res(fn.return_type, 64);
+        chunk.count = rows;
+        fn.function(chunk, es, res);
+        return res;
+      };
+      auto floats = [&](Vector &list) {
+        std::ostringstream o;
+        auto e = ListVector::GetData(list)[0];
+        auto v = FlatVector::GetData<float>(ListVector::GetEntry(list));
+        o << "[";
+        for (idx_t i = 0; i < e.length; i++) {
+          o << (i ? "," : "");
+          if (std::isnan(v[e.offset + i])) o << "NaN";      // what Python's json reads
+          else o << std::setprecision(9) << v[e.offset + i];
+        }
+        o << "]";
+        return o.str();
+      };
+      AggRun run(db.aggregates.at("sum_to_triple_3_3"), 1);
+      auto cols = Cols("abcdef", all, false);
+      run.Update(cols, {0, 0, 0, 0, 0});
+      Vector triple = run.Finalize();
+      DataChunk lt;      // linreg_train(triple, 0, 0.001, 0, 200, true, false)
+      lt.data = {triple, constant(LogicalTypeId::INTEGER, 0), constant(LogicalTypeId::FLOAT, 0.001),
+                 constant(LogicalTypeId::FLOAT, 0), constant(LogicalTypeId::INTEGER, 200),
+                 constant(LogicalTypeId::BOOLEAN, 1), constant(LogicalTypeId::BOOLEAN, 0)};
+      Vector lparams = call("linreg_train", lt, 1);
+      out << ",\"linreg_params\":" << floats(lparams);
+      DataChunk lp;      // linreg_predict(params, false, false, b, c, d, e, f) — dictionary vectors
+      lp.data = {lparams, constant(LogicalTypeId::BOOLEAN, 0), constant(LogicalTypeId::BOOLEAN, 0)};
+      for (auto &c : Cols("bcdef", all, true)) lp.data.push_back(c);
+      Vector lpred = call("linreg_predict", lp, 5);
+      out << ",\"linreg_pred\":[";
+      for (int i = 0; i < 5; i++) out << (i ? "," : "") << std::setprecision(9) << FlatVector::GetData<float>(lpred)[i];
+      out << "]";
+      DataChunk dt;      // lda_train(triple, 0, 0.1, false): class = column d
+      dt.data = {triple, constant(LogicalTypeId::INTEGER, 0), constant(LogicalTypeId::FLOAT, 0.1),
+                 constant(LogicalTypeId::BOOLEAN, 0)};
+      Vector dparams = call("lda_train", dt, 1);
+      out << ",\"lda_params\":" << floats(dparams);
+      DataChunk dp;      // lda_predict(params, false, a, b, c, e, f)
+      dp.data = {dparams, constant(LogicalTypeId::BOOLEAN, 0)};
+      for (auto &c : Cols("abcef", all, false)) dp.data.push_back(c);
+      Vector dpred = call("lda_predict", dp, 5);
+      out << ",\"lda_pred\":[";
+      for (int i = 0; i < 5; i++) out << (i ? "," : "") << FlatVector::GetData<int32_t>(dpred)[i];
+      out << "]";
     }
     out << "}";
     printf("%s\n", out.str().c_str());

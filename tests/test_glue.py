@@ -25,7 +25,8 @@ def test_glue_compiles_against_the_api_stand_in():
 
 
 @pytest.mark.gpu
-def test_glue_callbacks_reproduce_reference_goldens(goldens):
+def test_glue_callbacks_reproduce_reference_goldens(goldens, ref_table):
+    ref_tables = ref_table
     subprocess.check_call(["make", "-s", "-C", GLUE, "glue_driver"])
     out = subprocess.run([os.path.join(GLUE, "glue_driver")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
@@ -33,7 +34,7 @@ def test_glue_callbacks_reproduce_reference_goldens(goldens):
 
     # registration (reference: duckdb_imputation_extension.cpp:48-180; grid widened to 0..20)
     assert doc["version"] == "v0.9.2"
-    assert doc["n_aggregates"] == 2 * (1 + 21 * 21 - 1) and doc["n_scalars"] == 4
+    assert doc["n_aggregates"] == 2 * (1 + 21 * 21 - 1) and doc["n_scalars"] == 8
     assert all(v for k, v in doc["has"].items() if k != "sum_to_triple_0_0")
     assert doc["has"]["sum_to_triple_0_0"] is False
 
@@ -50,3 +51,20 @@ def test_glue_callbacks_reproduce_reference_goldens(goldens):
     assert doc["nb_lift_all"] == _expected(goldens, "test_nb_lift.py", 0)
     assert doc["multiply"] == _expected(goldens, "test_mul.py", 0)
     assert doc["nb_multiply"] == _expected(goldens, "test_nb_mul.py", 0)
+
+    # consumers (load_ml, duckdb_imputation_extension.cpp:182-249): the glue's constant-argument and
+    # DataChunk plumbing must give what the C ABI gives when called directly on the golden triple
+    import numpy as np
+    import cofactor_hip
+    from triple_fmt import dict_to_blob
+    t = ref_tables["test_sum.py"]
+    blob = dict_to_blob(_expected(goldens, "test_sum.py", 0)[0])
+    lparams = cofactor_hip.linreg_train(blob, 0, 0.001, 0.0, 200, True, False)
+    assert np.allclose(doc["linreg_params"], lparams, rtol=1e-6, atol=1e-6, equal_nan=True)
+    ctx = cofactor_hip.Context(0)
+    want = ctx.linreg_predict(lparams, t.num(["b", "c"]), t.cat(["d", "e", "f"]))
+    assert np.allclose(doc["linreg_pred"], want, rtol=1e-6, atol=1e-6)
+    dparams = cofactor_hip.lda_train(blob, 0, 0.1, False)
+    assert np.allclose(doc["lda_params"], dparams, rtol=1e-6, atol=1e-6)
+    assert doc["lda_pred"] == list(ctx.lda_predict(dparams, t.num(["a", "b", "c"]), t.cat(["e", "f"])))
+    ctx.close()
