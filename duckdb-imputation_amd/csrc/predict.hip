@@ -1,8 +1,9 @@
 // Per-row predictors over device-resident columns for the models ml.cpp trains (SURVEY.md §8f
 // N2): out[row] = W . [1, x, onehot(keys)] (+ Gaussian noise) for linreg_predict
 // (ML::linreg_impute, ML/regression.cpp:397-508), argmax over classes for lda_predict
-// (LDA_impute, ML/lda.cpp:421-590).  HBM-bound: every input column is read once, coalesced, one
-// row per lane; the model (a few KB) sits in LDS.
+// (LDA_impute, ML/lda.cpp:421-590).  HBM-bound: every input column is read once, one row per
+// lane; the model (a few KB) sits in LDS.  Under a row filter each wave compacts the selected
+// rows first, so a sparse filter costs the bytes of the lines it touches, not idle lanes.
 #include "device.hpp"
 
 namespace cofactor {
@@ -10,6 +11,14 @@ namespace cofactor {
 namespace {
 
 constexpr int PREDICT_THREADS = 256;
+constexpr int PREDICT_QCAP = 64 + 256;  // per wave: < 64 rows carried over + one 256-row chunk
+
+// offset (in doubles) of the row queues inside the dynamic LDS block
+__host__ __device__ inline size_t predict_queue_offset(int F, int M, int C, int KT, int w_in_lds) {
+  const size_t bytes = (w_in_lds ? (size_t)C * (1 + F + KT) * 8 : 0) + ((size_t)KT + M + 1) * 4 +
+                       ((size_t)F + M) * PREDICT_THREADS * 4;
+  return (bytes + 7) / 8;
+}
 
 // counter-based generator: two uniforms per (seed, row), independent of the launch geometry
 __device__ inline unsigned long long mix64(unsigned long long z) {
@@ -27,13 +36,18 @@ __global__ __launch_bounds__(PREDICT_THREADS) void predict_kernel(
     unsigned long long seed) {
   extern __shared__ double smem[];
   // LDS: [W (C * P doubles) if it fits][keys KT][kbegin M+1][x tile F x 256][slot tile M x 256]
+  //      [per wave: queue of selected rows, QCAP u32]
   const int P = 1 + F + KT;
   double *w_l = smem;
   int32_t *keys_l = reinterpret_cast<int32_t *>(smem + (w_in_lds ? (size_t)C * P : 0));
   int32_t *kb_l = keys_l + KT;
   float *x_l = reinterpret_cast<float *>(kb_l + M + 1);
   int32_t *s_l = reinterpret_cast<int32_t *>(x_l + (size_t)F * PREDICT_THREADS);
-  const int tid = threadIdx.x;
+  // 8-byte aligned: everything before it is a multiple of 8 bytes or padded to one below
+  unsigned long long *queue =
+      reinterpret_cast<unsigned long long *>(smem + predict_queue_offset(F, M, C, KT, w_in_lds)) +
+      (threadIdx.x >> 6) * PREDICT_QCAP;
+  const int tid = threadIdx.x, lane = tid & 63;
   if (w_in_lds)
     for (int i = tid; i < C * P; i += PREDICT_THREADS) w_l[i] = W[i];
   for (int i = tid; i < KT; i += PREDICT_THREADS) keys_l[i] = keys[i];
@@ -41,9 +55,7 @@ __global__ __launch_bounds__(PREDICT_THREADS) void predict_kernel(
   __syncthreads();
   const double *w = w_in_lds ? w_l : W;
 
-  for (uint64_t row = (uint64_t)blockIdx.x * PREDICT_THREADS + tid; row < rows;
-       row += (uint64_t)gridDim.x * PREDICT_THREADS) {
-    if (mask && !mask[row]) continue;
+  auto predict_row = [&](uint64_t row) {
     for (int f = 0; f < F; f++) x_l[f * PREDICT_THREADS + tid] = __builtin_nontemporal_load(num.p[f] + row);
     for (int c = 0; c < M; c++) {
       const int32_t key = __builtin_nontemporal_load(cat.p[c] + row);
@@ -78,16 +90,48 @@ __global__ __launch_bounds__(PREDICT_THREADS) void predict_kernel(
       }
       out_f[row] = (float)best;
     }
+  };
+
+  const uint64_t wave = ((uint64_t)blockIdx.x * PREDICT_THREADS + tid) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * PREDICT_THREADS) >> 6;
+  if (!mask) {
+    for (uint64_t base = wave * 64; base < rows; base += nwaves * 64)
+      if (base + lane < rows) predict_row(base + lane);
+    return;
   }
+  // Row filter: a wave scans 256 mask bytes at a time, appends the selected rows to its queue
+  // (ballot + prefix popcount) and predicts them 64 at a time, so that a sparse filter (the 10 %
+  // missing values of one column) still keeps every lane busy.
+  const bool aligned = (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
+  unsigned qn = 0;                                    // queue fill, the same in every lane
+  for (uint64_t base = wave * 256; base < rows; base += nwaves * 256) {
+    const uint64_t r0 = base + 4 * (uint64_t)lane;
+    unsigned mbits = 0;
+    if (aligned && r0 + 4 <= rows) mbits = *reinterpret_cast<const unsigned *>(mask + r0);
+    else
+      for (int j = 0; j < 4; j++)
+        if (r0 + j < rows) mbits |= (unsigned)mask[r0 + j] << (8 * j);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool sel = ((mbits >> (8 * j)) & 0xFFu) != 0;
+      const unsigned long long b = __ballot(sel);
+      if (sel) queue[qn + __popcll(b & ((1ull << lane) - 1))] = r0 + j;
+      qn += (unsigned)__popcll(b);
+    }
+    while (qn >= 64) {                                // the top 64 entries, one per lane
+      predict_row(queue[qn - 64 + lane]);
+      qn -= 64;
+    }
+  }
+  if ((unsigned)lane < qn) predict_row(queue[lane]);
 }
 
 }  // namespace
 
 size_t predict_lds_bytes(int F, int M, int C, int KT, size_t lds_limit, int *w_in_lds) {
-  const size_t fixed = ((size_t)KT + M + 1) * 4 + ((size_t)F + M) * PREDICT_THREADS * 4;
-  const size_t wbytes = (size_t)C * (1 + F + KT) * 8;
-  *w_in_lds = fixed + wbytes <= lds_limit;
-  return fixed + (*w_in_lds ? wbytes : 0) + 8;
+  const size_t qbytes = (size_t)(PREDICT_THREADS / 64) * PREDICT_QCAP * 8;
+  *w_in_lds = predict_queue_offset(F, M, C, KT, 1) * 8 + qbytes <= lds_limit;
+  return predict_queue_offset(F, M, C, KT, *w_in_lds) * 8 + qbytes;
 }
 
 hipError_t launch_predict(bool argmax, const NumCols &num, const CatCols &cat, int F, int M, int C,
