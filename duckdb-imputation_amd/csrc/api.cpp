@@ -474,7 +474,11 @@ cofactor_status stage_flush(cofactor_agg *a) {
 }
 
 // Device tables + host accumulator -> one HostTriple (synchronises).
-cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = false) {
+// pair_lists (optional): the device pair tables are written there as sorted (key1, key2, count)
+// lists, one per column pair, instead of into out.pair — finalize's fast path for states whose
+// host side holds no keys (no map node per entry: a 1000-key column pair has 1e6 of them).
+cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = false,
+                         std::vector<std::vector<PairVal>> *pair_lists = nullptr) {
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   cofactor_status s = stage_flush(a);
@@ -546,13 +550,16 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
         std::sort(order[c].begin(), order[c].end(), [&](int x, int y) { return key_of[c][x] < key_of[c][y]; });
       }
       int q = 0;
+      if (pair_lists) pair_lists->assign(tri(a->m), {});
       for (int c1 = 0; c1 < a->m; c1++)
         for (int c2 = c1; c2 < a->m; c2++, q++) {
           auto &tab = out.pair[q];
           for (int k1 : order[c1])
             for (int k2 : order[c2]) {
               const unsigned long long v = p[L.p_off[q] + (size_t)k1 * L.kc[c2] + k2];
-              if (v) tab.emplace_hint(tab.end(), std::make_pair(key_of[c1][k1], key_of[c2][k2]), (double)v);
+              if (!v) continue;
+              if (pair_lists) (*pair_lists)[q].push_back({key_of[c1][k1], key_of[c2][k2], (double)v});
+              else tab.emplace_hint(tab.end(), std::make_pair(key_of[c1][k1], key_of[c2][k2]), (double)v);
             }
         }
     }
@@ -855,10 +862,29 @@ cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap
   CTX_LOCK(a->ctx);
   if (!a->blob_cache_valid || a->stage_rows > 0) {
     HostTriple snap;
-    cofactor_status s = snapshot(a, snap);
+    bool host_has_keys = false;       // keys merged in on the host (combine, lifted triples)
+    for (auto const &c : a->host.col) host_has_keys = host_has_keys || !c.empty();
+    for (auto const &t : a->host.pair) host_has_keys = host_has_keys || !t.empty();
+    std::vector<std::vector<PairVal>> pairs;
+    const bool direct = a->kind == COFACTOR_TRIPLE && a->m > 0 && !host_has_keys;
+    cofactor_status s = snapshot(a, snap, false, direct ? &pairs : nullptr);
     if (s != COFACTOR_OK) return s;
     a->blob_cache.clear();
-    snap.encode(a->blob_cache);
+    if (direct) {
+      pairs.resize(tri(a->m));
+      size_t extra = 0;
+      for (auto const &l : pairs) extra += 1 + 3 * l.size();
+      snap.encode_without_pairs(a->blob_cache);
+      a->blob_cache.reserve(a->blob_cache.size() + extra);
+      for (auto const &l : pairs) {
+        a->blob_cache.push_back((double)l.size());
+        for (auto const &e : l) {
+          a->blob_cache.push_back(e.k1); a->blob_cache.push_back(e.k2); a->blob_cache.push_back(e.val);
+        }
+      }
+    } else {
+      snap.encode(a->blob_cache);
+    }
     a->blob_cache_valid = true;
   }
   return emit_blob(a->blob_cache, out, cap, needed);

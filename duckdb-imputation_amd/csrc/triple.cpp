@@ -154,6 +154,17 @@ bool HostTriple::add(const HostTriple &o, std::string &err) {
 }
 
 void HostTriple::encode(std::vector<double> &out) const {
+  encode_without_pairs(out);
+  if (kind) return;
+  for (auto const &tab : pair) {
+    out.push_back((double)tab.size());
+    for (auto const &kv : tab) {
+      out.push_back(kv.first.first); out.push_back(kv.first.second); out.push_back(kv.second);
+    }
+  }
+}
+
+void HostTriple::encode_without_pairs(std::vector<double> &out) const {
   out.push_back(kind); out.push_back(n); out.push_back(m); out.push_back(N);
   out.insert(out.end(), lin.begin(), lin.end());
   out.insert(out.end(), quad.begin(), quad.end());
@@ -167,12 +178,6 @@ void HostTriple::encode(std::vector<double> &out) const {
       out.push_back((double)col[c].size());
       for (auto const &kv : col[c]) { out.push_back(kv.first); out.push_back(kv.second[k + 1]); }
     }
-  for (auto const &tab : pair) {
-    out.push_back((double)tab.size());
-    for (auto const &kv : tab) {
-      out.push_back(kv.first.first); out.push_back(kv.first.second); out.push_back(kv.second);
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

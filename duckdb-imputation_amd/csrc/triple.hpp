@@ -46,6 +46,7 @@ struct HostTriple {
   // this += other (SumStateCombine)
   bool add(const HostTriple &o, std::string &err);
   void encode(std::vector<double> &out) const;  // SumStateFinalize order
+  void encode_without_pairs(std::vector<double> &out) const;  // everything before quad_cat
 };
 
 // Scalar ring ops on decoded blobs.
