@@ -399,8 +399,9 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
   if (skipped > 0) {                              // redo the left-out tiles, dictionary pass included
     const uint64_t trows = (uint64_t)skipped * FUSED_TILE_ROWS;
     unsigned *temp = nullptr;
-    HIP_TRY(hipMalloc((void **)&temp, sizeof(unsigned) * trows * (size_t)(a->n + a->m)));
-    hipError_t ge = launch_gather_tiles(num, cat, a->n, a->m, ctx->skip + 1, skipped, temp, trows, st);
+    HIP_TRY(hipMalloc((void **)&temp, sizeof(unsigned) * trows * (size_t)(a->n + a->m) + (mask ? trows : 0)));
+    uint8_t *tmask = mask ? reinterpret_cast<uint8_t *>(temp + trows * (size_t)(a->n + a->m)) : nullptr;
+    hipError_t ge = launch_gather_tiles(num, cat, a->n, a->m, ctx->skip + 1, skipped, temp, trows, st, mask, tmask);
     cofactor_status s = ge == hipSuccess ? COFACTOR_OK : hip_fail(ge, "launch_gather_tiles");
     if (s == COFACTOR_OK) {
       NumCols gnum{};
@@ -408,8 +409,9 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       for (int k = 0; k < a->n; k++) gnum.p[k] = reinterpret_cast<const float *>(temp) + (size_t)k * trows;
       for (int c = 0; c < a->m; c++) gcat.p[c] = reinterpret_cast<const int32_t *>(temp) + (size_t)(a->n + c) * trows;
       const double before = a->dev_rows;
-      s = update_device_impl(a, gnum, gcat, trows, /*allow_optimistic=*/false);
-      a->dev_rows = before;                       // these rows are counted once, below
+      s = update_device_impl(a, gnum, gcat, trows, /*allow_optimistic=*/false, tmask);
+      a->dev_rows = before;                       // these rows are counted once, below (a filter's kept
+                                                  // rows were counted on the device by that call)
     }
     (void)hipStreamSynchronize(st);
     (void)hipFree(temp);
@@ -772,7 +774,7 @@ cofactor_status cofactor_agg_update_device_masked(cofactor_agg *a, const float *
   DeviceGuard guard(a->ctx->device);
   cofactor_status s = stage_flush(a);
   if (s != COFACTOR_OK) return s;
-  return update_device_impl(a, num, cat, rows, /*allow_optimistic=*/false, d_mask);
+  return update_device_impl(a, num, cat, rows, /*allow_optimistic=*/true, d_mask);
 }
 
 cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *num,

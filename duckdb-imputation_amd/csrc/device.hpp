@@ -119,8 +119,10 @@ hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, c
                         unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
                         hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr,
                         unsigned long long *kept = nullptr);
+// packs the listed 256-row tiles of every column (and of the row filter, if any) into temp
 hipError_t launch_gather_tiles(const NumCols &num, const CatCols &cat, int n, int m, const unsigned *list,
-                               unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream);
+                               unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream,
+                               const uint8_t *mask = nullptr, uint8_t *temp_mask = nullptr);
 
 // ---- per-row predictors (predict.hip) ------------------------------------------------------------
 // out = W . [1, x_0..x_{F-1}, onehot(keys of the M key columns)] per class; argmax picks the class

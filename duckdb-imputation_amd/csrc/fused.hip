@@ -501,10 +501,13 @@ __global__ __launch_bounds__(256) void fused_pairs_fold_kernel(const unsigned *_
 // temp[col][i * 256 + j] = col[list[i] * 256 + j]: the tiles the optimistic pass left out, packed
 __global__ __launch_bounds__(256) void gather_tiles_kernel(NumCols num, CatCols cat, int n, int m,
                                                            const unsigned *__restrict__ list, unsigned count,
-                                                           unsigned *__restrict__ temp, uint64_t temp_stride) {
+                                                           unsigned *__restrict__ temp, uint64_t temp_stride,
+                                                           const uint8_t *__restrict__ mask,
+                                                           uint8_t *__restrict__ temp_mask) {
   for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
     const uint64_t src = (uint64_t)list[i] * TR + threadIdx.x;
     const uint64_t dst = (uint64_t)i * TR + threadIdx.x;
+    if (mask) temp_mask[dst] = mask[src];
     for (int c = 0; c < n + m; c++) {
       const unsigned *col = c < n ? reinterpret_cast<const unsigned *>(num.p[c])
                                   : reinterpret_cast<const unsigned *>(cat.p[c - n]);
@@ -616,10 +619,11 @@ hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, c
 }
 
 hipError_t launch_gather_tiles(const NumCols &num, const CatCols &cat, int n, int m, const unsigned *list,
-                               unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream) {
+                               unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream,
+                               const uint8_t *mask, uint8_t *temp_mask) {
   if (count == 0) return hipSuccess;
   hipLaunchKernelGGL(gather_tiles_kernel, dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, num, cat,
-                     n, m, list, count, temp, temp_stride);
+                     n, m, list, count, temp, temp_stride, mask, temp_mask);
   return hipGetLastError();
 }
 

@@ -330,6 +330,35 @@ def test_masked_update_equals_filtered_rows(ctx, n, m, keys):
     agg.close()
 
 
+def test_masked_update_after_reset_skips_the_dictionary_pass_and_still_meets_new_keys(ctx):
+    """Second and later masked updates (each column of a MICE sweep) run without the dictionary
+    pass; tiles in which a key shows up that the dictionaries do not hold yet — in a kept or in a
+    filtered row — are redone with their slice of the filter."""
+    import torch
+    rng = np.random.default_rng(77)
+    rows, n, m = 40_000, 3, 4
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [rng.integers(0, 5, rows).astype(np.int32) for _ in range(m)]
+    mask = (rng.random(rows) < 0.9).astype(np.uint8)
+    agg = ctx.aggregate(n, m)
+    dev = lambda cols: [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in cols]
+    agg.update_device_masked(dev(num), dev(cat), torch.from_numpy(mask).cuda())   # builds the dictionaries
+    agg.reset()
+    cat2 = [c.copy() for c in cat]
+    cat2[1][1000] = 91; mask[1000] = 1             # new key in a kept row
+    cat2[2][20_000] = 92; mask[20_000] = 0         # new key in a filtered row
+    cat2[0][39_990] = 93; mask[39_990] = 1         # new key in the < 256-row tail
+    dm = torch.from_numpy(mask).cuda()
+    ctx.profile(True); ctx.profile_read()
+    agg.update_device_masked(dev(num), dev(cat2), dm)
+    keep = mask.astype(bool)
+    ref = orc.State(orc.FAITHFUL).update([c[keep] for c in num], [c[keep] for c in cat2])
+    assert blob_to_dict(agg.finalize()) == blob_to_dict(ref.finalize())
+    prof = ctx.profile_read(); ctx.profile(False)
+    assert prof["fused_launches"] >= 1
+    agg.close()
+
+
 def test_nb_aggregate(ctx):
     rng = np.random.default_rng(21)
     rows = 30_000
