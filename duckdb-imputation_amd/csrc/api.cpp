@@ -92,8 +92,12 @@ struct cofactor_agg {
   bool blob_cache_valid = false;
   CatLayout L{};
   CatDevice D{};
-  // host staging for update_host (pinned) and its device mirror
+  // host staging for update_host (pinned) and its device mirror, both double-buffered: while
+  // buffer b is on its way to the device (copy + kernels, asynchronous), chunks land in b ^ 1
   uint64_t stage_cap = 0, stage_rows = 0;
+  int stage_buf = 0;
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
   float *h_num = nullptr;
   int32_t *h_cat = nullptr;
   float *d_num = nullptr;
@@ -456,22 +460,29 @@ cofactor_status stage_flush(cofactor_agg *a) {
   CTX_LOCK(a->ctx);
   hipStream_t st = a->ctx->stream;
   const uint64_t cap = a->stage_cap, rows = a->stage_rows;
+  const int b = a->stage_buf;
   NumCols num{};
   CatCols cat{};
   for (int k = 0; k < a->n; k++) {
-    HIP_TRY(hipMemcpyAsync(a->d_num + k * cap, a->h_num + k * cap, rows * sizeof(float),
-                           hipMemcpyHostToDevice, st));
-    num.p[k] = a->d_num + k * cap;
+    const uint64_t off = ((uint64_t)b * a->n + k) * cap;
+    HIP_TRY(hipMemcpyAsync(a->d_num + off, a->h_num + off, rows * sizeof(float), hipMemcpyHostToDevice, st));
+    num.p[k] = a->d_num + off;
   }
   for (int c = 0; c < a->m; c++) {
-    HIP_TRY(hipMemcpyAsync(a->d_cat + c * cap, a->h_cat + c * cap, rows * sizeof(int32_t),
-                           hipMemcpyHostToDevice, st));
-    cat.p[c] = a->d_cat + c * cap;
+    const uint64_t off = ((uint64_t)b * a->m + c) * cap;
+    HIP_TRY(hipMemcpyAsync(a->d_cat + off, a->h_cat + off, rows * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    cat.p[c] = a->d_cat + off;
   }
   cofactor_status s = update_device_impl(a, num, cat, rows);
   if (s != COFACTOR_OK) return s;
-  HIP_TRY(hipStreamSynchronize(st));              // the pinned buffer is refilled next
+  HIP_TRY(hipEventRecord(a->stage_ev[b], st));    // buffer b is free again once this has passed
+  a->stage_busy[b] = true;
+  a->stage_buf = b ^ 1;
   a->stage_rows = 0;
+  if (a->stage_busy[b ^ 1]) {                      // the buffer filled next must have left the host
+    HIP_TRY(hipEventSynchronize(a->stage_ev[b ^ 1]));
+    a->stage_busy[b ^ 1] = false;
+  }
   return COFACTOR_OK;
 }
 
@@ -704,6 +715,8 @@ void cofactor_agg_destroy(cofactor_agg *a) {
   if (a->cat_ready) cat_free(a->D);
   if (a->h_num) (void)hipHostFree(a->h_num);
   if (a->h_cat) (void)hipHostFree(a->h_cat);
+  for (auto &e : a->stage_ev)
+    if (e) (void)hipEventDestroy(e);
   (void)hipFree(a->d_num);
   (void)hipFree(a->d_cat);
   delete a;
@@ -789,19 +802,20 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
   if (!a->stage_cap) {
     a->stage_cap = (uint64_t)env_long("COFACTOR_STAGE_ROWS", 1 << 18);
     if (a->n) {
-      HIP_TRY(hipHostMalloc((void **)&a->h_num, sizeof(float) * a->n * a->stage_cap, hipHostMallocDefault));
-      HIP_TRY(hipMalloc((void **)&a->d_num, sizeof(float) * a->n * a->stage_cap));
+      HIP_TRY(hipHostMalloc((void **)&a->h_num, sizeof(float) * 2 * a->n * a->stage_cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void **)&a->d_num, sizeof(float) * 2 * a->n * a->stage_cap));
     }
     if (a->m) {
-      HIP_TRY(hipHostMalloc((void **)&a->h_cat, sizeof(int32_t) * a->m * a->stage_cap, hipHostMallocDefault));
-      HIP_TRY(hipMalloc((void **)&a->d_cat, sizeof(int32_t) * a->m * a->stage_cap));
+      HIP_TRY(hipHostMalloc((void **)&a->h_cat, sizeof(int32_t) * 2 * a->m * a->stage_cap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void **)&a->d_cat, sizeof(int32_t) * 2 * a->m * a->stage_cap));
     }
+    for (auto &e : a->stage_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   uint64_t done = 0;
   while (done < rows) {
     const uint64_t take = std::min(rows - done, a->stage_cap - a->stage_rows);
     for (int k = 0; k < a->n; k++) {
-      float *dst = a->h_num + k * a->stage_cap + a->stage_rows;
+      float *dst = a->h_num + ((uint64_t)a->stage_buf * a->n + k) * a->stage_cap + a->stage_rows;
       const float *src = num[k];
       const uint32_t *sel = num_sel ? num_sel[k] : nullptr;
       if (!sel && !row_idx) std::memcpy(dst, src + done, take * sizeof(float));
@@ -812,7 +826,7 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
         }
     }
     for (int c = 0; c < a->m; c++) {
-      int32_t *dst = a->h_cat + c * a->stage_cap + a->stage_rows;
+      int32_t *dst = a->h_cat + ((uint64_t)a->stage_buf * a->m + c) * a->stage_cap + a->stage_rows;
       const int32_t *src = cat[c];
       const uint32_t *sel = cat_sel ? cat_sel[c] : nullptr;
       if (!sel && !row_idx) std::memcpy(dst, src + done, take * sizeof(int32_t));
