@@ -53,7 +53,7 @@ __device__ __forceinline__ unsigned fhash(int32_t key, int cap) {
 // codes of 4 keys in the LDS copy of a dictionary (NO_CODE = 16 if absent), packed as 4 x u16.  The four
 // probe chains advance together, so their LDS round trips overlap.  One copy in the code object
 // (called 2.5 times per loader wave and tile): the loader loop has to stay small.
-__device__ __noinline__ uint2 lds_lookup4(const unsigned long long *slots, const int32_t *codes, int cap,
+__device__ __forceinline__ uint2 lds_lookup4(const unsigned long long *slots, const int32_t *codes, int cap,
                                           uint4 keys) {
   const unsigned key[4] = {keys.x, keys.y, keys.z, keys.w};
   unsigned h[4], cd[4];
@@ -188,16 +188,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   auto fetch = [&](uint4 (&pre)[LDX], unsigned &pre_mask, uint64_t t) {
     const uint64_t r0 = t * TR + 4 * (uint64_t)lane;
     // row filter of this lane's 4 rows, one byte each (the launcher checked the 4-byte alignment)
-    pre_mask = mask ? *reinterpret_cast<const unsigned *>(mask + r0) : 0x01010101u;
+    // (without a filter the same load reads 4 bytes of column 0 and is ignored: see below)
+    const uint8_t *mbase = mask ? mask : reinterpret_cast<const uint8_t *>(n ? (const void *)num.p[0] : (const void *)cat.p[0]);
+    const unsigned mword = *reinterpret_cast<const unsigned *>(mbase + r0);
+    pre_mask = mask ? mword : 0x01010101u;
+    // Every slot loads, a slot past the last column re-reads the last one: a fixed number of
+    // loads per call lets the compiler wait with vmcnt(N) for the tile it parks and leave the
+    // younger tile's loads in flight (a conditional load forces vmcnt(0), i.e. a ring of one).
 #pragma unroll
     for (int i = 0; i < LDX; i++) {
-      const int vc = tw + 4 * i;                           // wave-uniform virtual column
-      if (vc < n + m) {
-        const unsigned *src = vc < n ? reinterpret_cast<const unsigned *>(num.p[vc])
-                                     : reinterpret_cast<const unsigned *>(cat.p[vc - n]);
-        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + r0));
-        pre[i] = __builtin_bit_cast(uint4, v);
-      }
+      const int vc = min(tw + 4 * i, n + m - 1);           // wave-uniform virtual column
+      const unsigned *src = vc < n ? reinterpret_cast<const unsigned *>(num.p[vc])
+                                   : reinterpret_cast<const unsigned *>(cat.p[vc - n]);
+      const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + r0));
+      pre[i] = __builtin_bit_cast(uint4, v);
     }
   };
   auto park = [&](const uint4 (&pre)[LDX], unsigned pre_mask, int b, unsigned stamp) {
@@ -415,11 +419,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     unsigned pmask[RING];
     uint64_t t = blockIdx.x;
     unsigned k = 1;                                         // per-workgroup tile counter = nf stamp
+    // (ntiles >= 1 and blockIdx.x < ntiles: the launcher sizes the grid that way)
 #pragma unroll
-    for (int r = 0; r < RING; r++)
-      if (t + r * G < ntiles) fetch(pre[r], pmask[r], t + r * G);
+    for (int r = 0; r < RING; r++) fetch(pre[r], pmask[r], min(t + r * G, ntiles - 1));
     if (t < ntiles) park(pre[0], pmask[0], 0, k);
-    if (t + RING * G < ntiles) fetch(pre[0], pmask[0], t + RING * G);
+    fetch(pre[0], pmask[0], min(t + RING * G, ntiles - 1));
     __syncthreads();
     int b = 0;
     while (t < ntiles) {
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       for (int r = 0; r < RING; r++) {                      // consuming tile j (j % RING == r)
         const int nx = (r + 1) % RING;
         if (t + G < ntiles) park(pre[nx], pmask[nx], b ^ 1, k + 1);
-        if (t + (RING + 1) * G < ntiles) fetch(pre[nx], pmask[nx], t + (RING + 1) * G);
+        fetch(pre[nx], pmask[nx], min(t + (RING + 1) * G, ntiles - 1));   // past the end: a harmless re-read
         __syncthreads();                                    // buffer b free, buffer b^1 complete
         t += G; b ^= 1; k++;
         if (t >= ntiles) break;
