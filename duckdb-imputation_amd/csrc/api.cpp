@@ -455,6 +455,34 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
   return COFACTOR_OK;
 }
 
+// (Re)allocates the double-buffered staging area for `cap` rows per buffer.  Only called with
+// both buffers empty on the host side; waits for copies still reading the old one.
+cofactor_status stage_alloc(cofactor_agg *a, uint64_t cap) {
+  CTX_LOCK(a->ctx);
+  if (a->stage_cap) {
+    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    if (a->h_num) (void)hipHostFree(a->h_num);
+    if (a->h_cat) (void)hipHostFree(a->h_cat);
+    (void)hipFree(a->d_num);
+    (void)hipFree(a->d_cat);
+    a->h_num = nullptr; a->h_cat = nullptr; a->d_num = nullptr; a->d_cat = nullptr;
+    a->stage_busy[0] = a->stage_busy[1] = false;
+  }
+  if (a->n) {
+    HIP_TRY(hipHostMalloc((void **)&a->h_num, sizeof(float) * 2 * a->n * cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&a->d_num, sizeof(float) * 2 * a->n * cap));
+  }
+  if (a->m) {
+    HIP_TRY(hipHostMalloc((void **)&a->h_cat, sizeof(int32_t) * 2 * a->m * cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&a->d_cat, sizeof(int32_t) * 2 * a->m * cap));
+  }
+  for (auto &e : a->stage_ev)
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  a->stage_cap = cap;
+  a->stage_buf = 0;
+  return COFACTOR_OK;
+}
+
 cofactor_status stage_flush(cofactor_agg *a) {
   if (a->stage_rows == 0) return COFACTOR_OK;
   CTX_LOCK(a->ctx);
@@ -799,17 +827,12 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
   if (rows == 0) return COFACTOR_OK;
   a->blob_cache_valid = false;
   DeviceGuard guard(a->ctx->device);
+  // Staging starts small and grows with the rows a state actually receives (x8 per full buffer up
+  // to COFACTOR_STAGE_ROWS): a GROUP BY with thousands of states must not pin 2 x 20 MB for each.
   if (!a->stage_cap) {
-    a->stage_cap = (uint64_t)env_long("COFACTOR_STAGE_ROWS", 1 << 18);
-    if (a->n) {
-      HIP_TRY(hipHostMalloc((void **)&a->h_num, sizeof(float) * 2 * a->n * a->stage_cap, hipHostMallocDefault));
-      HIP_TRY(hipMalloc((void **)&a->d_num, sizeof(float) * 2 * a->n * a->stage_cap));
-    }
-    if (a->m) {
-      HIP_TRY(hipHostMalloc((void **)&a->h_cat, sizeof(int32_t) * 2 * a->m * a->stage_cap, hipHostMallocDefault));
-      HIP_TRY(hipMalloc((void **)&a->d_cat, sizeof(int32_t) * 2 * a->m * a->stage_cap));
-    }
-    for (auto &e : a->stage_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint64_t max_rows = (uint64_t)std::max(2048L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
+    cofactor_status s = stage_alloc(a, std::min<uint64_t>(max_rows, 4096));
+    if (s != COFACTOR_OK) return s;
   }
   uint64_t done = 0;
   while (done < rows) {
@@ -841,6 +864,11 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
     if (a->stage_rows == a->stage_cap) {
       cofactor_status s = stage_flush(a);
       if (s != COFACTOR_OK) return s;
+      const uint64_t max_rows = (uint64_t)std::max(2048L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
+      if (a->stage_cap < max_rows) {
+        s = stage_alloc(a, std::min(max_rows, a->stage_cap * 8));
+        if (s != COFACTOR_OK) return s;
+      }
     }
   }
   return COFACTOR_OK;

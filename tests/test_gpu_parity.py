@@ -426,6 +426,28 @@ def test_host_chunks_with_selection_vectors_group_by(ctx):
         aggs[g].close()
 
 
+def test_group_by_with_many_states_and_growing_staging(ctx):
+    """A GROUP BY with hundreds of states: each state's staging starts at 4096 rows and grows only
+    with the rows it receives (one big group crosses several growth steps, the rest stay small)."""
+    rng = np.random.default_rng(99)
+    rows, n, m, groups = 120_000, 2, 2, 300
+    num, cat = int_table(rng, rows, n, m)
+    gid = rng.integers(1, groups, rows).astype(np.int32)
+    gid[rng.random(rows) < 0.7] = 0                          # group 0 takes most rows
+    aggs = [ctx.aggregate(n, m) for _ in range(groups)]
+    for lo in range(0, rows, 2048):
+        hi = min(rows, lo + 2048)
+        order = np.argsort(gid[lo:hi], kind="stable").astype(np.uint32)
+        bounds = np.searchsorted(gid[lo:hi][order], np.arange(groups + 1))
+        pnum, pcat = [c[lo:hi] for c in num], [c[lo:hi] for c in cat]
+        for g in np.unique(gid[lo:hi]):
+            aggs[g].update_host(pnum, pcat, row_idx=order[bounds[g]:bounds[g + 1]])
+    want = orc.grouped_update(num, cat, gid, groups, mode=orc.FAITHFUL)
+    for g in range(groups):
+        assert blob_to_dict(aggs[g].finalize()) == blob_to_dict(want[g].finalize()), g
+        aggs[g].close()
+
+
 def test_concurrent_states_on_one_context(ctx):
     """DuckDB calls update from several worker threads at once, each on its own states; all of them
     share one cofactor_ctx (stream + scratch buffers).  ctypes releases the GIL, so these really

@@ -7,7 +7,9 @@ os.environ["COFACTOR_LIB"] = os.path.join(ROOT, "duckdb-imputation_amd", "cofact
 import torch
 import cofactor_hip
 
-rows, n, m, K = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50_000_000, 10, 10, 16
+rows, n, m = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50_000_000, 10, 10
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+os.environ.setdefault("COFACTOR_NO_FUSED", "1")      # this tool is about the two-kernel path
 g = torch.Generator(device="cuda").manual_seed(1)
 num = [torch.rand(rows, generator=g, device="cuda") for _ in range(n)]
 cat = [torch.randint(0, K, (rows,), generator=g, device="cuda", dtype=torch.int32) for _ in range(m)]
