@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--keys", type=int, default=16, help="distinct keys per categorical column")
     ap.add_argument("--cpu-sample-rows", type=float, default=6e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-dist", action="store_true", help="run the multi-GPU code path at the current world size")
     return ap.parse_args()
 
 
@@ -87,8 +88,14 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # --rehearse-dist: take the N > 1 code path (RCCL process group, all-reduce of the partial
+    # triple, barriers) with whatever world size there is, e.g. 1 on a one-GPU box
+    use_dist = world > 1 or args.rehearse_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     rows, n, m = int(args.rows), args.num_cols, args.cat_cols
@@ -102,7 +109,7 @@ def main():
     def step():
         agg.reset()
         agg.update_device_ptrs(num_ptrs, cat_ptrs, rows)
-        if world > 1:
+        if use_dist:
             # ONE RCCL all-reduce of the dense partial triple (+ host merge of categorical lists)
             return cdist.allreduce_triple(agg, dist, device)
         return agg.finalize()
@@ -110,7 +117,7 @@ def main():
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,7 +134,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -148,7 +155,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_%d_%d" % (kname, n, m))
+                tj = json.load(open(tpath))
+                key = "%s_%d_%d" % (kname, n, m)
+                # the committed PMC figure is per launch at the row count it was measured with
+                if tj.get(key + "__rows") == rows:
+                    traffic = tj.get(key)
             except Exception:
                 traffic = None
         out = {
@@ -170,7 +181,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(torch, num, cat, args.cpu_sample_rows, n, m)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     agg.close()

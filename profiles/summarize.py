@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (gpurun_out/…) into the small summaries kept under profiles/.
 
-    python profiles/summarize.py r01 gpurun_out/prof_r01 gpurun_out/pmc_fetch_r01 gpurun_out/pmc_write_r01 [tag] [traffic-key]
+    python profiles/summarize.py r01 gpurun_out/prof_r01 gpurun_out/pmc_fetch_r01 gpurun_out/pmc_write_r01 [tag] [traffic-key] [rows]
 
 Writes profiles/<round>_kernel_stats[_tag].csv (kernel names cut to 100 chars),
 profiles/<round>_pmc[_tag].json (per-kernel FETCH_SIZE / WRITE_SIZE per launch, raw and corrected)
@@ -34,6 +34,7 @@ def main():
     rnd, prof, fetch, write = sys.argv[1:5]
     tag = ("_" + sys.argv[5]) if len(sys.argv) > 5 else ""
     key = sys.argv[6] if len(sys.argv) > 6 else None
+    nrows = int(float(sys.argv[7])) if len(sys.argv) > 7 else None
     stats = find(prof, "_kernel_stats.csv")
     rows = list(csv.DictReader(open(stats)))
     out = os.path.join(HERE, "%s_kernel_stats%s.csv" % (rnd, tag))
@@ -74,6 +75,8 @@ def main():
         if best:
             traffic[key] = best["hbm_bytes_per_launch"]
             traffic[key + "__source"] = "profiles/%s_pmc%s.json" % (rnd, tag)
+            if nrows:
+                traffic[key + "__rows"] = nrows      # bench.py reports the figure only at this size
             json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     print(open(out).read())
     print(json.dumps(pmc, indent=1))
