@@ -89,10 +89,17 @@ constexpr unsigned NO_CODE = 16u;
 constexpr unsigned ROW_OFF = 17u;   // code of every column of a row the row filter dropped (matches no i either)
 __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
   unsigned w[4] = {cv.x, cv.y, cv.z, cv.w};
+  // per 16-bit half: d = code ^ i, min(d, 1) is 0 on a match and 1 otherwise, and
+  // 0x3F80 + min * 0xC080 (mod 2^16) is bf16 1.0 or 0: three packed VALU ops per two rows.
+  // (Inline asm: hipcc turns the same thing written with ushort2 vectors into scalar compares.)
+  const unsigned ones = 0x00010001u, neg = 0xC080C080u, one_bf = 0x3F803F80u;
 #pragma unroll
   for (int e = 0; e < 4; e++) {
-    const unsigned hit = (0x00200020u - (w[e] ^ ii)) & 0x00200020u;    // 0x20 per matching half
-    w[e] = __umul24(hit, 0x1FCu);                                         // 0x20 * 0x1FC = 0x3F80 = bf16 1.0
+    unsigned m, r;
+    const unsigned d = w[e] ^ ii;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(d), "v"(ones));
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(neg), "v"(one_bf));
+    w[e] = r;
   }
   return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
 }
