@@ -830,8 +830,8 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
   // Staging starts small and grows with the rows a state actually receives (x8 per full buffer up
   // to COFACTOR_STAGE_ROWS): a GROUP BY with thousands of states must not pin 2 x 20 MB for each.
   if (!a->stage_cap) {
-    const uint64_t max_rows = (uint64_t)std::max(2048L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
-    cofactor_status s = stage_alloc(a, std::min<uint64_t>(max_rows, 4096));
+    const uint64_t max_rows = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
+    cofactor_status s = stage_alloc(a, std::min<uint64_t>(max_rows, 512));
     if (s != COFACTOR_OK) return s;
   }
   uint64_t done = 0;
@@ -864,7 +864,7 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
     if (a->stage_rows == a->stage_cap) {
       cofactor_status s = stage_flush(a);
       if (s != COFACTOR_OK) return s;
-      const uint64_t max_rows = (uint64_t)std::max(2048L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
+      const uint64_t max_rows = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
       if (a->stage_cap < max_rows) {
         s = stage_alloc(a, std::min(max_rows, a->stage_cap * 8));
         if (s != COFACTOR_OK) return s;

@@ -3,6 +3,8 @@ masked aggregate -> train -> predict in place, per incomplete column.  There is 
 this in the reference (its driver needs a DuckDB connection); the checks are the ones the
 algorithm guarantees: present values are never touched, missing ones are filled, and the
 model-based fill beats the AVG / MODE fill it starts from."""
+import os
+
 import numpy as np
 import pytest
 
@@ -79,4 +81,27 @@ def test_mice_iteration_improves_on_the_baseline_fill():
                                          [k0[xn][:2000], truth["k1"][xn][:2000]])
     z = (x0[xn][:2000] - mean_pred) / float(models["x0"][-1])
     assert abs(z.mean()) < 0.1 and abs(z.std() - 1) < 0.1
+    ctx.close()
+
+
+def test_mice_through_the_rccl_path_matches_the_single_process_run():
+    """The sharded loop exchanges only the all-reduced triple per column.  On a one-GPU box the
+    RCCL process group has one rank: the run goes through export -> all-reduce -> import and the
+    all-gather of the key lists, and must fill in exactly what the plain run fills in (same seed,
+    same rank)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29643")
+    t1, _ = _table(60_000, seed=9)
+    t2, _ = _table(60_000, seed=9)
+    ctx = cofactor_hip.Context(0)
+    mice.run_mice(ctx, t1, iterations=1, seed=3)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        mice.run_mice(ctx, t2, iterations=1, seed=3, dist=dist, device=torch.device("cuda", 0))
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(t1.cat["k0"], t2.cat["k0"])
+    assert torch.allclose(t1.num["x0"], t2.num["x0"], rtol=1e-5, atol=1e-5)
     ctx.close()

@@ -427,7 +427,7 @@ def test_host_chunks_with_selection_vectors_group_by(ctx):
 
 
 def test_group_by_with_many_states_and_growing_staging(ctx):
-    """A GROUP BY with hundreds of states: each state's staging starts at 4096 rows and grows only
+    """A GROUP BY with hundreds of states: each state's staging starts at 512 rows and grows only
     with the rows it receives (one big group crosses several growth steps, the rest stay small)."""
     rng = np.random.default_rng(99)
     rows, n, m, groups = 120_000, 2, 2, 300
