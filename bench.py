@@ -167,11 +167,12 @@ def main():
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 inputs, f32 MFMA products, f64 accumulation", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "sum_to_triple_%d_%d over %d rows per GPU (%d total), uniform[0,1) "
                                    "float32 columns%s, resident in HBM" %
                                    (n, m, rows, total_rows, (", %d int32 columns with %d keys" % (m, args.keys)) if m else ""),
                        "rows_per_gpu": rows, "num_cols": n, "cat_cols": m,
+                       "arithmetic": "f32 inputs and MFMA products, f64 accumulation, exact integer counts",
                        "parallelism": "row-sharded x%d, one RCCL all-reduce of the dense partial triple" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
