@@ -197,8 +197,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     // row filter of this lane's 4 rows, one byte each (the launcher checked the 4-byte alignment)
     // (without a filter the same load reads 4 bytes of column 0 and is ignored: see below)
     const uint8_t *mbase = mask ? mask : reinterpret_cast<const uint8_t *>(n ? (const void *)num.p[0] : (const void *)cat.p[0]);
-    const unsigned mword = *reinterpret_cast<const unsigned *>(mbase + r0);
-    pre_mask = mask ? mword : 0x01010101u;
+    // raw word: park() decides whether it means anything (a select here would make the wave wait
+    // for this load, and so for every older load of the ring, right after issuing it)
+    pre_mask = *reinterpret_cast<const unsigned *>(mbase + r0);
     // Every slot loads, a slot past the last column re-reads the last one: a fixed number of
     // loads per call lets the compiler wait with vmcnt(N) for the tile it parks and leave the
     // younger tile's loads in flight (a conditional load forces vmcnt(0), i.e. a ring of one).
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       pre[i] = __builtin_bit_cast(uint4, v);
     }
   };
-  auto park = [&](const uint4 (&pre)[LDX], unsigned pre_mask, int b, unsigned stamp) {
+  auto park = [&](const uint4 (&pre)[LDX], unsigned raw_mask, int b, unsigned stamp) {
+    const unsigned pre_mask = mask ? raw_mask : 0x01010101u;   // row filter of this lane's 4 rows
     float *xt = xt_of(b);
     unsigned short *pt = pt_of(b);
     unsigned short *codes = codes_of(b);

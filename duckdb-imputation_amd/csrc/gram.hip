@@ -11,13 +11,17 @@
 //     [column][row] with a +4-float column stride;
 //   * each wave owns 64 rows of the tile; per 4 rows every lane reads its A and B operand columns
 //     with two ds_read_b128 and issues 4 v_mfma_f32_4x4x1_16b_f32 — one MFMA per row covers all
-//     <= 15 4x4 blocks of the upper triangle (device.hpp);
+//     <= 15 4x4 blocks of the upper triangle (device.hpp); for n <= 12 the spare blocks of the
+//     instruction take further rows (16 / 4 / 2 rows per MFMA at n <= 4 / 8 / 12);
+//   * narrow tables keep several tiles' loads in flight (a tile is only n KiB): a register ring
+//     of 5 / 3 / 2 tiles at n <= 4 / 8 / 16, with unconditional loads so the waits are vmcnt(k);
 //   * fp32 MFMA chains are cut every FLUSH_TILES tiles and folded into fp64 registers (the
 //     reference's fp32 running sums saturate at 2^24);
 //   * per-workgroup fp64 images go to a [slot][workgroup] scratch array and a second small kernel
 //     adds them, in a fixed order, into the aggregate's accumulator image.
 #include "device.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace cofactor {
@@ -56,6 +60,18 @@ __device__ __forceinline__ float4 load_rows4_tail(const float *__restrict__ col,
 __device__ int g_gram_ablate = 0;   // timing experiments only: 1 = no MFMA loop, 2 = loads only
 #endif
 
+// Rows one MFMA handles: the instruction has 16 independent 4x4 blocks and the upper triangle of
+// NB column blocks needs NPAIR of them, so for n <= 12 the spare blocks take further ROWS (block
+// b serves block pair b % NPAIR of row b / NPAIR); their accumulators are added at the end.
+__host__ __device__ constexpr int gram_rows_per_mfma(int n) {
+  return n <= 4 ? 16 : (n <= 8 ? 4 : (n <= 12 ? 2 : 1));
+}
+// Tiles whose loads a thread keeps in flight: a 256-row tile is only n KiB, so narrow tables need
+// a deeper ring to cover the HBM latency (about 80 KiB in flight per CU at 4 workgroups).
+__host__ __device__ constexpr int gram_ring_depth(int n) {
+  return n <= 4 ? 5 : (n <= 8 ? 3 : (n <= 16 ? 2 : 1));
+}
+
 template <int N, bool ALIGNED>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64_t rows,
                                                             double *__restrict__ partials,
@@ -65,6 +81,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   constexpr int NBC = 4 * NB;                     // data columns incl. zero padding to 4*NB
   constexpr int CS = GRAM_COL_STRIDE;
   constexpr int LD = (N * 64 + GRAM_THREADS - 1) / GRAM_THREADS;  // float4 loads / thread / tile
+  constexpr int RPM = gram_rows_per_mfma(N);
+  constexpr int DEPTH = gram_ring_depth(N);
   // columns [0,N) data, [N,NBC) zero padding, column NBC all-zero (operand of unused blocks)
   constexpr int TILE_FLOATS = (NBC + 1) * CS > 8 * GRAM_ACC_LEN ? (NBC + 1) * CS : 8 * GRAM_ACC_LEN;
   __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS];  // also the wave-fold scratch
@@ -73,11 +91,12 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int colA = NBC, colB = NBC;
+  int colA = NBC, colB = NBC, rsub = 0;
   {
     const int b = lane >> 2, t = lane & 3;
-    if (b < NPAIR) {
-      int bi = 0, rem = b;
+    if (b < RPM * NPAIR) {
+      rsub = b / NPAIR;
+      int bi = 0, rem = b % NPAIR;
       while (rem >= NB - bi) { rem -= NB - bi; bi++; }
       colA = 4 * bi + t;
       colB = 4 * (bi + rem) + t;
@@ -85,42 +104,46 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   }
   for (int i = tid; i < (NBC + 1 - N) * CS; i += GRAM_THREADS) tile[N * CS + i] = 0.f;
 
-  const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
-  float4 pre[LD];
-  unsigned pre_mask = 0x01010101u;                // row mask of this lane's 4 rows, one byte each
-  auto fetch = [&](uint64_t t) {
-    const uint64_t r0 = t * GRAM_TILE_ROWS;
-    if (mask) {                                   // masked update: rows with a zero byte contribute nothing
-      const uint64_t r = r0 + 4 * lane;
-      if (r + 4 <= rows && (reinterpret_cast<uintptr_t>(mask) & 3) == 0) {
-        pre_mask = *reinterpret_cast<const unsigned *>(mask + r);
-      } else {
-        pre_mask = 0u;
-        for (int e = 0; e < 4; e++)
-          if (r + e < rows) pre_mask |= (unsigned)mask[r + e] << (8 * e);
-      }
-    }
-    if (r0 + GRAM_TILE_ROWS <= rows) {            // whole tile in range: straight-line loads
+  // Whole tiles go through the register ring: their loads are unconditional (a ring slot past
+  // the end re-reads the last whole tile), so the compiler waits with vmcnt(k) for the oldest
+  // slot only.  The partial last tile is handled once, after the loop, by the workgroup it
+  // falls to.
+  const uint64_t nfull = rows / GRAM_TILE_ROWS;
+  // (the row filter is 4-byte aligned here: launch_gram peels the rows before the first aligned
+  // byte off into a launch of their own; without a filter the same load reads column 0)
+  const uint8_t *mbase = mask ? mask : reinterpret_cast<const uint8_t *>(cols.p[0]);
+  auto fetch = [&](float4 (&pre)[LD], unsigned &pre_mask, uint64_t t) {
+    const uint64_t r0 = t * GRAM_TILE_ROWS + 4 * (uint64_t)lane;
+    // raw word; park() decides whether it means anything.  (Looking at it here would make the
+    // wave wait for this load right away, and with it for every older load of the ring.)
+    pre_mask = *reinterpret_cast<const unsigned *>(mbase + r0);
 #pragma unroll
-      for (int i = 0; i < LD; i++) {
-        const int col = wave + 4 * i;             // wave-uniform: q = tid + 256 i, col = q / 64
-        if (4 * i + 3 < N || col < N) pre[i] = load_rows4_full<ALIGNED>(cols.p[col], r0 + 4 * lane);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < LD; i++) {
-        const int col = wave + 4 * i;
-        if (4 * i + 3 < N || col < N) pre[i] = load_rows4_tail(cols.p[col], r0 + 4 * lane, rows);
-      }
+    for (int i = 0; i < LD; i++) {
+      const int col = min(wave + 4 * i, N - 1);   // wave-uniform: q = tid + 256 i, col = q / 64
+      pre[i] = load_rows4_full<ALIGNED>(cols.p[col], r0);
     }
   };
-  auto park = [&]() {
+  auto fetch_tail = [&](float4 (&pre)[LD], unsigned &pre_mask, uint64_t t) {
+    const uint64_t r0 = t * GRAM_TILE_ROWS + 4 * (uint64_t)lane;
+    pre_mask = 0x01010101u;
+    if (mask) {
+      pre_mask = 0u;
+      for (int e = 0; e < 4; e++)
+        if (r0 + e < rows) pre_mask |= (unsigned)mask[r0 + e] << (8 * e);
+    }
+#pragma unroll
+    for (int i = 0; i < LD; i++) {
+      const int col = min(wave + 4 * i, N - 1);
+      pre[i] = load_rows4_tail(cols.p[col], r0, rows);
+    }
+  };
+  auto park = [&](const float4 (&pre)[LD], unsigned pre_mask) {
 #pragma unroll
     for (int i = 0; i < LD; i++) {
       const int col = wave + 4 * i;
       if (4 * i + 3 < N || col < N) {
         float4 v = pre[i];
-        if (mask) {
+        if (mask) {                               // filtered rows contribute nothing
           v.x = (pre_mask & 0x000000FFu) ? v.x : 0.f;
           v.y = (pre_mask & 0x0000FF00u) ? v.y : 0.f;
           v.z = (pre_mask & 0x00FF0000u) ? v.z : 0.f;
@@ -134,47 +157,25 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   f32x2 ls_lo = {0.f, 0.f}, ls_hi = {0.f, 0.f};         // per-lane column sums of the A operand
   double dq0 = 0, dq1 = 0, dq2 = 0, dq3 = 0, dl = 0;
-  const float *pa = tile + colA * CS + wave * 64;
-  const float *pb = tile + colB * CS + wave * 64;
-
-  uint64_t t = blockIdx.x;
-  if (t < ntiles) fetch(t);
+  // this wave's 64 rows of the tile; a lane serving row group rsub starts 4 * rsub rows in and
+  // steps over the RPM groups of each round
+  const float *pa = tile + colA * CS + wave * 64 + 4 * rsub;
+  const float *pb = tile + colB * CS + wave * 64 + 4 * rsub;
   int since_flush = 0;
-#ifdef COFACTOR_DEV_ABLATE
-  const int ablate = g_gram_ablate;
-#endif
-  while (t < ntiles) {
-#ifdef COFACTOR_DEV_ABLATE
-    if (ablate == 2) {
-      for (int i = 0; i < LD; i++) asm volatile("" ::"v"(pre[i].x), "v"(pre[i].y), "v"(pre[i].z), "v"(pre[i].w));
-      const uint64_t tn2 = t + gridDim.x;
-      if (tn2 < ntiles) fetch(tn2);
-      t = tn2;
-      continue;
-    }
-#endif
-    park();
-    __syncthreads();
-    const uint64_t tn = t + gridDim.x;
-    if (tn < ntiles) fetch(tn);                   // next tile's loads fly under this tile's MFMAs
-#ifdef COFACTOR_DEV_ABLATE
-    if (ablate == 1) { __syncthreads(); t = tn; continue; }
-#endif
-    {
-      const f32x4 *va = reinterpret_cast<const f32x4 *>(pa);
-      const f32x4 *vb = reinterpret_cast<const f32x4 *>(pb);
+  auto crunch = [&]() {
+    const f32x4 *va = reinterpret_cast<const f32x4 *>(pa);
+    const f32x4 *vb = reinterpret_cast<const f32x4 *>(pb);
 #pragma unroll 4
-      for (int it = 0; it < 16; it++) {
-        const f32x4 a = va[it], b = vb[it];
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc3, 0, 0, 0);
-        ls_lo += __builtin_shufflevector(a, a, 0, 1);       // v_pk_add_f32 on the aligned halves
-        ls_hi += __builtin_shufflevector(a, a, 2, 3);
-      }
+    for (int it = 0; it < 16 / RPM; it++) {
+      const f32x4 a = va[it * RPM], b = vb[it * RPM];
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc3, 0, 0, 0);
+      ls_lo += __builtin_shufflevector(a, a, 0, 1);       // v_pk_add_f32 on the aligned halves
+      ls_hi += __builtin_shufflevector(a, a, 2, 3);
     }
-    if (++since_flush == FLUSH_TILES) {
+    if (++since_flush == FLUSH_TILES * RPM) {             // still <= 64 fp32 adds per chain
       dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
       dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
       dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
@@ -184,8 +185,42 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
       ls_lo = ls_hi = f32x2{0.f, 0.f};
       since_flush = 0;
     }
-    __syncthreads();                              // everyone done reading before the next park()
-    t = tn;
+  };
+
+#ifdef COFACTOR_DEV_ABLATE
+  const int ablate = g_gram_ablate;
+#endif
+  const uint64_t G = gridDim.x;
+  uint64_t t = blockIdx.x;
+  if (t < nfull) {
+    float4 pre[DEPTH][LD];
+    unsigned pmask[DEPTH];
+#pragma unroll
+    for (int r = 0; r < DEPTH; r++) fetch(pre[r], pmask[r], min(t + r * G, nfull - 1));
+    while (t < nfull) {
+#pragma unroll
+      for (int r = 0; r < DEPTH; r++) {           // tile t sits in ring slot r
+        park(pre[r], pmask[r]);
+        __syncthreads();
+        fetch(pre[r], pmask[r], min(t + DEPTH * G, nfull - 1));   // flies under DEPTH tiles of MFMAs
+#ifdef COFACTOR_DEV_ABLATE
+        if (ablate == 0)
+#endif
+        crunch();
+        __syncthreads();                          // everyone done reading before the next park()
+        t += G;
+        if (t >= nfull) break;
+      }
+    }
+  }
+  if (rows % GRAM_TILE_ROWS && blockIdx.x == nfull % G) {   // the partial last tile
+    float4 pre[LD];
+    unsigned pmask;
+    fetch_tail(pre, pmask, nfull);
+    park(pre, pmask);
+    __syncthreads();
+    crunch();
+    __syncthreads();
   }
   dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
   dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
@@ -193,7 +228,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
   dl += (double)((ls_lo[0] + ls_lo[1]) + (ls_hi[0] + ls_hi[1]));
 
-  // fold the 4 waves (fixed order) through LDS, then one image per workgroup
+  // fold the 4 waves and the RPM row groups (fixed order) through LDS: one image per workgroup,
+  // in the layout of device.hpp (lane 4 * pair + t)
   double *red = reinterpret_cast<double *>(tile);  // 4 waves x 320 doubles = 10 KiB
   static_assert(sizeof(double) * 4 * GRAM_ACC_LEN <= sizeof(float) * TILE_FLOATS,
                 "wave fold scratch must fit the tile");
@@ -206,8 +242,14 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   mine[4 * 64 + lane] = dl;
   __syncthreads();
   for (int i = tid; i < GRAM_ACC_LEN; i += GRAM_THREADS) {
-    const double v = ((red[i] + red[GRAM_ACC_LEN + i]) + red[2 * GRAM_ACC_LEN + i]) +
-                     red[3 * GRAM_ACC_LEN + i];
+    const int ln = i & 63;
+    double v = 0;
+    if (ln < 4 * NPAIR)
+#pragma unroll
+      for (int rs = 0; rs < RPM; rs++) {
+        const int j = i + 4 * NPAIR * rs;
+        v += ((red[j] + red[GRAM_ACC_LEN + j]) + red[2 * GRAM_ACC_LEN + j]) + red[3 * GRAM_ACC_LEN + j];
+      }
     partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
   }
 }
@@ -265,22 +307,10 @@ hipError_t launch_count_mask(const uint8_t *mask, uint64_t rows, unsigned long l
   return hipGetLastError();
 }
 
-hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
-                       double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-                       const uint8_t *mask) {
-  if (rows == 0 || n == 0) return hipSuccess;
-#ifdef COFACTOR_DEV_ABLATE
-  {
-    const char *v = getenv("COFACTOR_GRAM_ABLATE");
-    int mask = v ? atoi(v) : 0;
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_ablate), &mask, sizeof(int), 0, hipMemcpyHostToDevice, stream);
-    (void)hipStreamSynchronize(stream);
-  }
-#endif
-  const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
-  if ((uint64_t)grid > ntiles) grid = (int)ntiles;
+// kernel for n columns over `rows` rows (filter, if any, 4-byte aligned unless rows < one tile)
+static hipError_t launch_gram_kernel(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
+                                     const uint8_t *mask, hipStream_t stream) {
   hipError_t e = hipErrorInvalidValue;
-  if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
   switch (n) {
 #define CASE(N) case N: e = launch_n<N>(cols, rows, grid, partials, mask, stream); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
@@ -288,7 +318,48 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
 #undef CASE
     default: return hipErrorInvalidValue;
   }
+  return e;
+}
+
+// kernel + fold of the per-workgroup images into acc
+static hipError_t launch_gram_rows(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
+                                   double *acc, hipStream_t stream, const uint8_t *mask) {
+  if (rows == 0) return hipSuccess;
+  const uint64_t ntiles = (rows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
+  if ((uint64_t)grid > ntiles) grid = (int)ntiles;
+  hipError_t e = launch_gram_kernel(cols, n, rows, grid, partials, mask, stream);
   if (e != hipSuccess) return e;
+  return launch_gram_fold(partials, grid, acc, stream);
+}
+
+hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, double *partials,
+                       double *acc, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                       const uint8_t *mask) {
+  if (rows == 0 || n == 0) return hipSuccess;
+#ifdef COFACTOR_DEV_ABLATE
+  {
+    const char *v = getenv("COFACTOR_GRAM_ABLATE");
+    int abl = v ? atoi(v) : 0;
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_gram_ablate), &abl, sizeof(int), 0, hipMemcpyHostToDevice, stream);
+    (void)hipStreamSynchronize(stream);
+  }
+#endif
+  hipError_t e;
+  if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
+  uint64_t head = 0;
+  if (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) {
+    // the kernel reads the filter of whole tiles as 4-byte words: the 1..3 rows before the first
+    // aligned byte go into a launch of their own (below one tile: byte-wise tail path)
+    head = std::min<uint64_t>(rows, 4 - (reinterpret_cast<uintptr_t>(mask) & 3));
+    if ((e = launch_gram_rows(cols, n, head, grid, partials, acc, stream, mask)) != hipSuccess) return e;
+  }
+  NumCols rest = cols;
+  for (int k = 0; k < n; k++) rest.p[k] = cols.p[k] + head;
+  const uint64_t rrows = rows - head;
+  if (rrows == 0) return ev1 ? hipEventRecord(ev1, stream) : hipSuccess;
+  const uint64_t ntiles = (rrows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
+  if ((uint64_t)grid > ntiles) grid = (int)ntiles;
+  if ((e = launch_gram_kernel(rest, n, rrows, grid, partials, mask ? mask + head : nullptr, stream)) != hipSuccess) return e;
   if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
   return launch_gram_fold(partials, grid, acc, stream);
 }
