@@ -162,11 +162,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   if (tid < 4) l_nf[tid] = 0u;                               // l_nf[0..1], l_skip[0..1]
 
   // ---- lane roles of the MFMA team -------------------------------------------------------------
-  int colA = NBC, colB = NBC;                              // Gram operand columns (gram.hip)
+  // Gram operand columns as in gram.hip: block b serves block pair b % NPAIR of row group
+  // b / NPAIR (RPM row groups per MFMA when the triangle leaves blocks of the instruction free)
+  constexpr int RPM = NPAIR <= 1 ? 16 : (NPAIR <= 3 ? 4 : (NPAIR <= 6 ? 2 : 1));
+  int colA = NBC, colB = NBC, rsub = 0;
   {
     const int b = lane >> 2, t = lane & 3;
-    if (b < NPAIR) {
-      int bi = 0, rem = b;
+    if (b < RPM * NPAIR) {
+      rsub = b / NPAIR;
+      int bi = 0, rem = b % NPAIR;
       while (rem >= NB - bi) { rem -= NB - bi; bi++; }
       colA = 4 * bi + t;
       colB = 4 * (bi + rem) + t;
@@ -379,11 +383,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     const unsigned short *pt = pt_of(b);
     const unsigned short *codes = codes_of(b);
     if (!(ablate & 4)) {
-      const f32x4 *va = reinterpret_cast<const f32x4 *>(xt + colA * XCS + tw * 64);
-      const f32x4 *vb = reinterpret_cast<const f32x4 *>(xt + colB * XCS + tw * 64);
+      const f32x4 *va = reinterpret_cast<const f32x4 *>(xt + colA * XCS + tw * 64 + 4 * rsub);
+      const f32x4 *vb = reinterpret_cast<const f32x4 *>(xt + colB * XCS + tw * 64 + 4 * rsub);
 #pragma unroll 4
-      for (int it = 0; it < 16; it++) {
-        const f32x4 a = va[it], bv = vb[it];
+      for (int it = 0; it < 16 / RPM; it++) {
+        const f32x4 a = va[it * RPM], bv = vb[it * RPM];
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], bv[0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], bv[1], acc1, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], bv[2], acc2, 0, 0, 0);
@@ -485,8 +489,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   // ---- end: Gram image of the workgroup, count / sum tables into the aggregate's HBM tables ---
   __syncthreads();
   const double *red = reinterpret_cast<const double *>(lds + cv.gsum);
-  for (int i = tid; i < GRAM_ACC_LEN; i += FUSED_THREADS) {
-    const double v = ((red[i] + red[GRAM_ACC_LEN + i]) + red[2 * GRAM_ACC_LEN + i]) + red[3 * GRAM_ACC_LEN + i];
+  for (int i = tid; i < GRAM_ACC_LEN; i += FUSED_THREADS) {   // 4 waves and RPM row groups, fixed order
+    double v = 0;
+    if ((i & 63) < 4 * NPAIR)
+#pragma unroll
+      for (int rs = 0; rs < RPM; rs++) {
+        const int j = i + 4 * NPAIR * rs;
+        v += ((red[j] + red[GRAM_ACC_LEN + j]) + red[2 * GRAM_ACC_LEN + j]) + red[3 * GRAM_ACC_LEN + j];
+      }
     partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
   }
   for (int i = tid; i < L.n_cnt; i += FUSED_THREADS)
