@@ -359,6 +359,32 @@ def test_masked_update_after_reset_skips_the_dictionary_pass_and_still_meets_new
     agg.close()
 
 
+@pytest.mark.parametrize("shift", [1, 2, 3])
+@pytest.mark.parametrize("n,m", [(5, 0), (3, 2)])
+def test_masked_update_with_a_filter_that_is_not_word_aligned(ctx, n, m, shift):
+    """The kernels read the row filter of whole tiles as 4-byte words; a filter starting 1..3 bytes
+    off a word boundary (a slice of a larger buffer) must give the same triple."""
+    import torch
+    rng = np.random.default_rng(600 + shift)
+    rows = 5_000 + shift
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [rng.integers(0, 6, rows).astype(np.int32) for _ in range(m)]
+    mask = (rng.random(rows) < 0.8).astype(np.uint8)
+    big = torch.zeros(rows + 8, dtype=torch.uint8, device="cuda")
+    dm = big[shift:shift + rows]
+    dm.copy_(torch.from_numpy(mask))
+    assert dm.data_ptr() % 4 == shift
+    dn = [torch.from_numpy(c).cuda() for c in num]
+    dc = [torch.from_numpy(c).cuda() for c in cat]
+    torch.cuda.synchronize()
+    agg = ctx.aggregate(n, m)
+    agg.update_device_masked(dn, dc, dm)
+    keep = mask.astype(bool)
+    ref = orc.State(orc.FAITHFUL).update([c[keep] for c in num], [c[keep] for c in cat])
+    assert blob_to_dict(agg.finalize()) == blob_to_dict(ref.finalize())
+    agg.close()
+
+
 def test_nb_aggregate(ctx):
     rng = np.random.default_rng(21)
     rows = 30_000
