@@ -80,3 +80,36 @@ def test_10_10_100M_rows_counts_exact(ctx):
                 want = [(a, b, float(pc[a * K + b])) for a in range(K) for b in range(K) if pc[a * K + b]]
                 assert [(e["key1"], e["key2"], e["value"]) for e in got["quad_cat"][q]] == want
             q += 1
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 7, 8, 10, 12, 13, 16])
+def test_narrow_tables_exact_through_the_tile_ring(ctx, n):
+    """Narrow tables run gram_kernel with a ring of several tiles per workgroup and several rows
+    per MFMA; the ring only reaches its steady state when a workgroup walks many tiles, i.e. above
+    about 1.6 M rows.  Integer-valued columns, ragged row count, with and without a row filter:
+    every sum must equal torch's int64 sums exactly."""
+    import torch
+    rows = 6_000_000 + 777
+    g = torch.Generator(device="cuda").manual_seed(100 + n)
+    ints = [torch.randint(0, 8, (rows,), generator=g, device="cuda", dtype=torch.int32) for _ in range(n)]
+    cols = [c.float() for c in ints]
+    mask = (torch.rand(rows, generator=g, device="cuda") < 0.7).to(torch.uint8)
+    torch.cuda.synchronize()
+    for keep in (None, mask):
+        agg = ctx.aggregate(n, 0)
+        if keep is None:
+            agg.update_device(cols, [])
+            sel = ints
+        else:
+            agg.update_device_masked(cols, [], keep)
+            sel = [c * keep.to(torch.int32) for c in ints]
+        got = blob_to_dict(agg.finalize())
+        agg.close()
+        assert got["N"] == (rows if keep is None else int(keep.sum()))
+        assert got["lin_agg"] == [float(int(c.sum(dtype=torch.int64))) for c in sel]
+        q = 0
+        for j in range(n):
+            for k in range(j, n):
+                want = int((sel[j] * ints[k]).sum(dtype=torch.int64))
+                assert got["quad_agg"][q] == float(want), (j, k)
+                q += 1
