@@ -14,7 +14,7 @@
 //     <= 15 4x4 blocks of the upper triangle (device.hpp); for n <= 12 the spare blocks of the
 //     instruction take further rows (16 / 4 / 2 rows per MFMA at n <= 4 / 8 / 12);
 //   * narrow tables keep several tiles' loads in flight (a tile is only n KiB): a register ring
-//     of 5 / 3 / 2 tiles at n <= 4 / 8 / 16, with unconditional loads so the waits are vmcnt(k);
+//     of 5 / 3 / 2 tiles at n <= 4 / 8 / 20, with unconditional loads so the waits are vmcnt(k);
 //   * fp32 MFMA chains are cut every FLUSH_TILES tiles and folded into fp64 registers (the
 //     reference's fp32 running sums saturate at 2^24);
 //   * per-workgroup fp64 images go to a [slot][workgroup] scratch array and a second small kernel
@@ -69,7 +69,7 @@ __host__ __device__ constexpr int gram_rows_per_mfma(int n) {
 // Tiles whose loads a thread keeps in flight: a 256-row tile is only n KiB, so narrow tables need
 // a deeper ring to cover the HBM latency (about 80 KiB in flight per CU at 4 workgroups).
 __host__ __device__ constexpr int gram_ring_depth(int n) {
-  return n <= 4 ? 5 : (n <= 8 ? 3 : (n <= 16 ? 2 : 1));
+  return n <= 4 ? 5 : (n <= 8 ? 3 : 2);
 }
 
 template <int N, bool ALIGNED>
