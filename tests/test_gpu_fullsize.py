@@ -113,3 +113,27 @@ def test_narrow_tables_exact_through_the_tile_ring(ctx, n):
                 want = int((sel[j] * ints[k]).sum(dtype=torch.int64))
                 assert got["quad_agg"][q] == float(want), (j, k)
                 q += 1
+
+
+@pytest.mark.parametrize("n", [4, 10, 20])
+def test_unaligned_columns_exact_through_the_tile_ring(ctx, n):
+    """Same as above for columns that are only 4-byte aligned (dword loads instead of dwordx4)."""
+    import torch
+    rows = 6_000_000 + 333
+    g = torch.Generator(device="cuda").manual_seed(200 + n)
+    ints = [torch.randint(0, 8, (rows + 1,), generator=g, device="cuda", dtype=torch.int32) for _ in range(n)]
+    cols = [c.float() for c in ints]
+    torch.cuda.synchronize()
+    agg = ctx.aggregate(n, 0)
+    agg.update_device_ptrs([c.data_ptr() + 4 for c in cols], [], rows)      # skip each column's first row
+    got = blob_to_dict(agg.finalize())
+    agg.close()
+    sel = [c[1:] for c in ints]
+    assert got["N"] == rows
+    assert got["lin_agg"] == [float(int(c.sum(dtype=torch.int64))) for c in sel]
+    q = 0
+    for j in range(n):
+        for k in range(j, n):
+            if j == k or (j + k) % 3 == 0:
+                assert got["quad_agg"][q] == float(int((sel[j] * sel[k]).sum(dtype=torch.int64))), (j, k)
+            q += 1
