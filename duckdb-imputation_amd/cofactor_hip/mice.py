@@ -28,6 +28,10 @@ class MiceTable:
         # WHERE col_IS_NULL IS FALSE wants the complement; the masks never change during a run
         self.num_keep = {k: (v == 0).to(v.dtype) for k, v in self.num_null.items()}
         self.cat_keep = {k: (v == 0).to(v.dtype) for k, v in self.cat_null.items()}
+        # the library works on its own stream: whatever torch still has queued on these tensors
+        # (the two lines above included) must have finished before the first kernel reads them
+        import torch
+        torch.cuda.synchronize()
 
 
 def _reduced_triple(agg, dist, device):
@@ -39,6 +43,8 @@ def _reduced_triple(agg, dist, device):
 def init_baseline(ctx, table, dist=None, device=None):
     """init_baseline (imputation/algorithms/partition.cpp:671-719): missing numeric values take
     the column's AVG over the present ones, missing keys its MODE (ties: the smallest key)."""
+    import torch
+    torch.cuda.synchronize(device)                 # torch stream -> library stream hand-over
     for name, keep in table.num_keep.items():
         agg = ctx.aggregate(1, 0)
         agg.update_device_masked([table.num[name]], [], keep)
@@ -46,6 +52,7 @@ def init_baseline(ctx, table, dist=None, device=None):
         agg.close()
         mean = float(b[4] / b[3]) if b[3] > 0 else 0.0
         table.num[name].masked_fill_(table.num_null[name].bool(), mean)
+        torch.cuda.synchronize(device)
     for name, keep in table.cat_keep.items():
         agg = ctx.aggregate(0, 1)
         agg.update_device_masked([], [table.cat[name]], keep)
@@ -55,6 +62,7 @@ def init_baseline(ctx, table, dist=None, device=None):
         keys, counts = b[5:5 + 2 * ln:2], b[6:6 + 2 * ln:2]
         mode = int(keys[int(np.argmax(counts))]) if ln else 0
         table.cat[name].masked_fill_(table.cat_null[name].bool(), mode)
+        torch.cuda.synchronize(device)
 
 
 def run_mice(ctx, table, iterations=1, dist=None, device=None, seed=0, shrinkage=0.001,
