@@ -167,6 +167,7 @@ class Context:
             rows = out.numel()
             _check_cols(num_cols, cat_cols, rows, mask)
             assert str(out.dtype) == "torch.float32" and out.is_cuda and out.is_contiguous()
+            _torch_handover([out])
             _check(lib().cofactor_linreg_predict_device(
                 self._h, prm.ctypes.data, prm.size, int(noise), int(normalize), seed,
                 _ptr_array([t.data_ptr() for t in num_cols]), len(num_cols),
@@ -192,6 +193,7 @@ class Context:
             rows = out.numel()
             _check_cols(num_cols, cat_cols, rows, mask)
             assert str(out.dtype) == "torch.int32" and out.is_cuda and out.is_contiguous()
+            _torch_handover([out])
             _check(lib().cofactor_lda_predict_device(
                 self._h, prm.ctypes.data, prm.size, int(normalize), int(emit_label),
                 _ptr_array([t.data_ptr() for t in num_cols]), len(num_cols),
@@ -207,6 +209,16 @@ class Context:
             _ptr_array([c.ctypes.data for c in num]), len(num),
             _ptr_array([c.ctypes.data for c in cat]), len(cat), rows, res.ctypes.data))
         return res
+
+
+def _torch_handover(tensors):
+    """The library runs on its own stream: wait for what torch has queued on its current stream
+    (fills, copies, generators writing these tensors) before a kernel of ours reads them."""
+    for t in tensors:
+        if t is not None and hasattr(t, "is_cuda") and t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+            return
 
 
 def _on_device(num_cols, cat_cols):
@@ -251,7 +263,9 @@ class Aggregate:
 
     def update_device(self, num_tensors, cat_tensors):
         """Columns as 1-D contiguous torch tensors on this context's GPU (float32 / int32).
-        The caller makes sure they are complete (torch.cuda.synchronize() or stream order)."""
+        Waits for torch's current stream first (update_device_ptrs does not: raw pointers are
+        the caller's responsibility)."""
+        _torch_handover(list(num_tensors) + list(cat_tensors))
         rows = None
         for t, want in [(t, "torch.float32") for t in num_tensors] + \
                        [(t, "torch.int32") for t in cat_tensors]:
@@ -265,6 +279,7 @@ class Aggregate:
     def update_device_masked(self, num_tensors, cat_tensors, mask):
         """Like update_device, keeping only rows whose byte in `mask` (uint8 device tensor) is non-zero."""
         assert str(mask.dtype) == "torch.uint8" and mask.is_cuda and mask.is_contiguous()
+        _torch_handover([mask])
         rows = mask.numel()
         for t in list(num_tensors) + list(cat_tensors):
             assert t.numel() == rows and t.is_cuda and t.is_contiguous()
