@@ -98,7 +98,10 @@ cofactor_status cofactor_agg_reset(cofactor_agg *agg);
  *
  * Device form: the columns are resident in this context's HBM (d_num[k] -> float[rows],
  * d_cat[c] -> int32[rows]; the pointer arrays themselves are host arrays).  Asynchronous on the
- * context stream.  This is the measured hot path. */
+ * context stream: work the caller queued on OTHER streams that writes these columns must have
+ * completed (or be ordered before the context stream, cofactor_ctx_stream) when this is called,
+ * and the columns must stay untouched until the stream has passed the update
+ * (cofactor_ctx_synchronize, or any finalize).  This is the measured hot path. */
 cofactor_status cofactor_agg_update_device(cofactor_agg *agg, const float *const *d_num,
                                            const int32_t *const *d_cat, uint64_t rows);
 
