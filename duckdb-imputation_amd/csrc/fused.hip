@@ -85,6 +85,7 @@ __device__ __forceinline__ uint2 lds_lookup4(const unsigned long long *slots, co
 // i (0..15) in both halves, so d = code ^ i is 0..31 in each 16-bit half and 0 only on a match:
 // 0x20 - d has bit 5 set exactly there, with no borrow between the halves.  Plain 32-bit ops
 // (hipcc scalarises 16-bit vector compares into v_cmp/v_cndmask/v_perm chains).
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 constexpr unsigned NO_CODE = 16u;
 constexpr unsigned ROW_OFF = 17u;   // code of every column of a row the row filter dropped (matches no i either)
 __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
@@ -305,14 +306,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     // 256 q and cell = 256 q + 16 code1 + code2: dword 128 q + 8 code1 + (code2 >> 1), upper half
     // when code2 is odd.  Diagonal pairs (c, c) only ever hit cells (k, k) with the column's own
     // counts: they are filled from the count table at the end instead.
+    const unsigned lp_base = (unsigned)(unsigned long long)(lds_u32 *)l_p;   // 32-bit LDS address
     unsigned row8[MC], half[MC], inc[MC];
 #pragma unroll
     for (int c = 0; c < MC; c++)
       if (c < m) {
         atomicAdd(&l_cnt[16 * c + cd[c]], 1u);
-        row8[c] = 8u * cd[c];
-        half[c] = cd[c] >> 1;
+        row8[c] = 32u * cd[c];                              // byte offset of the row in a pair table
+        half[c] = lp_base + 4u * (cd[c] >> 1);              // LDS address of the dword inside row 0
         inc[c] = 1u << ((cd[c] & 1u) * 16u);
+        // keep the three in registers: left alone the compiler recomputes them from the code
+        // for every one of the m(m-1)/2 pairs (5 VALU per pair instead of 1)
+        asm volatile("" : "+v"(row8[c]), "+v"(half[c]), "+v"(inc[c]));
       }
     int q = 0;
 #pragma unroll
@@ -320,7 +325,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
 #pragma unroll
       for (int c2 = c1; c2 < MC; c2++)
         if (c2 < m) {
-          if (c2 != c1) atomicAdd(&l_p[128 * q + row8[c1] + half[c2]], inc[c2]);
+          if (c2 != c1)                                     // one v_add + ds_add_u32 offset:512q
+            __hip_atomic_fetch_add((lds_u32 *)(unsigned long long)(row8[c1] + half[c2] + 512u * q),
+                                   inc[c2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           q++;
         }
     if (l_nf[b] == stamp) {                                 // rare: pieces8 fed 0 for inf / nan
