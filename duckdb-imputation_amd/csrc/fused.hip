@@ -86,6 +86,7 @@ __device__ __forceinline__ uint2 lds_lookup4(const unsigned long long *slots, co
 // 0x20 - d has bit 5 set exactly there, with no borrow between the halves.  Plain 32-bit ops
 // (hipcc scalarises 16-bit vector compares into v_cmp/v_cndmask/v_perm chains).
 typedef __attribute__((address_space(3))) unsigned lds_u32;
+constexpr int DIRECT_KEYS = 256;        // keys 0..255 of a column are looked up in a byte table
 constexpr unsigned NO_CODE = 16u;
 constexpr unsigned ROW_OFF = 17u;   // code of every column of a row the row filter dropped (matches no i either)
 __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
@@ -109,7 +110,7 @@ constexpr int FUSED_THREADS = 768;      // waves 0-3 loaders, 4-7 counters, 8-11
 constexpr int TEAM = 256;
 
 struct FusedCarve {   // byte offsets into the dynamic LDS block
-  int xt, xt_stride, pt, pt_stride, codes, codes_stride, s, slot, dcode, cnt, pairs, nf, gsum, total;
+  int xt, xt_stride, pt, pt_stride, codes, codes_stride, s, slot, dcode, cnt, pairs, nf, gsum, direct, total;
 };
 
 template <int NB, int NBB, int M>
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   unsigned *l_p = reinterpret_cast<unsigned *>(lds + cv.pairs);   // two 16-bit cells per dword
   unsigned *l_nf = reinterpret_cast<unsigned *>(lds + cv.nf);     // [buffer]: stamp of a tile holding inf / nan
   unsigned *l_skip = l_nf + 2;                                    // [buffer]: stamp of a tile with an unknown key
+  unsigned char *l_direct = lds + cv.direct;                      // [column][key 0..255] -> code (NO_CODE if absent)
+  unsigned char *l_far = l_direct + M * DIRECT_KEYS;              // [column]: the dictionary holds a key outside 0..255
   auto xt_of = [&](int b) { return reinterpret_cast<float *>(lds + cv.xt + b * cv.xt_stride); };
   auto pt_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.pt + b * cv.pt_stride); };
   auto codes_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.codes + b * cv.codes_stride); };
@@ -161,6 +164,22 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   for (int i = tid; i < L.n_s; i += FUSED_THREADS) l_s[i] = 0.0;
   for (int i = tid; i < n_pw; i += FUSED_THREADS) l_p[i] = 0u;
   if (tid < 4) l_nf[tid] = 0u;                               // l_nf[0..1], l_skip[0..1]
+  // Small non-negative keys (the usual encoding of a categorical column) skip the hash probe: a
+  // byte table per column maps key 0..255 to its code.  A column whose dictionary holds any
+  // other key keeps probing (flag per column).
+  for (int i = tid; i < M * DIRECT_KEYS; i += FUSED_THREADS) l_direct[i] = (unsigned char)NO_CODE;
+  if (tid < 32) l_far[tid] = 0;
+  __syncthreads();
+  for (int c = 0; c < m; c++)
+    for (int i = tid; i < L.ht_cap[c]; i += FUSED_THREADS) {
+      const unsigned long long sv = l_slot[L.ht_off[c] + i];
+      const int32_t cdv = l_dcode[L.ht_off[c] + i];
+      if (sv != 0ull && cdv >= 0) {
+        const unsigned key = (unsigned)(sv & 0xFFFFFFFFull);
+        if (key < (unsigned)DIRECT_KEYS) l_direct[c * DIRECT_KEYS + key] = (unsigned char)cdv;
+        else l_far[c] = 1;
+      }
+    }
 
   // ---- lane roles of the MFMA team -------------------------------------------------------------
   // Gram operand columns as in gram.hip: block b serves block pair b % NPAIR of row group
@@ -258,7 +277,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
         const int cap = L.ht_cap[c];
         uint2 packed;
         if (ablate & 8) packed = make_uint2((pre[i].x & 15u) | ((pre[i].y & 15u) << 16), (pre[i].z & 15u) | ((pre[i].w & 15u) << 16));
-        else packed = lds_lookup4(slots, dc, cap, pre[i]);
+        else if (!l_far[c]) {                               // wave-uniform: byte table
+          const unsigned char *dt = l_direct + c * DIRECT_KEYS;
+          const unsigned kx = pre[i].x, ky = pre[i].y, kz = pre[i].z, kw = pre[i].w;
+          const unsigned cx = kx < (unsigned)DIRECT_KEYS ? dt[kx] : NO_CODE, cy = ky < (unsigned)DIRECT_KEYS ? dt[ky] : NO_CODE;
+          const unsigned cz = kz < (unsigned)DIRECT_KEYS ? dt[kz] : NO_CODE, cw = kw < (unsigned)DIRECT_KEYS ? dt[kw] : NO_CODE;
+          packed = make_uint2(cx | (cy << 16), cz | (cw << 16));
+        } else packed = lds_lookup4(slots, dc, cap, pre[i]);
         *reinterpret_cast<uint2 *>(&codes[c * PTS + 4 * lane]) = packed;
         // optimistic mode (skip != nullptr): a tile that meets a key the dictionary does not
         // know yet is left out as a whole and redone by the host after a dictionary pass
@@ -564,6 +589,7 @@ FusedCarve make_carve(const CatLayout &L, int nb) {
   c.pairs = take((size_t)((L.n_p + 1) / 2) * 4, 4);
   c.nf = take(16, 4);
   c.gsum = take(sizeof(double) * 4 * GRAM_ACC_LEN, 8);
+  c.direct = take((size_t)L.m * DIRECT_KEYS + 32, 4);     // per key column: code of key 0..255, then the flags
   c.total = (int)((o + 15) / 16 * 16);
   return c;
 }
