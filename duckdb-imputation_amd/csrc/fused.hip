@@ -246,29 +246,42 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       const int vc = tw + 4 * i;
       if (vc < n) {
         // filtered rows contribute x = 0 to the Gram and to the per-key sums
-        const unsigned u[4] = {(pre_mask & 0x000000FFu) ? pre[i].x : 0u, (pre_mask & 0x0000FF00u) ? pre[i].y : 0u,
-                               (pre_mask & 0x00FF0000u) ? pre[i].z : 0u, (pre_mask & 0xFF000000u) ? pre[i].w : 0u};
+        unsigned u[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+        if (mask) {
+          u[0] = (pre_mask & 0x000000FFu) ? u[0] : 0u; u[1] = (pre_mask & 0x0000FF00u) ? u[1] : 0u;
+          u[2] = (pre_mask & 0x00FF0000u) ? u[2] : 0u; u[3] = (pre_mask & 0xFF000000u) ? u[3] : 0u;
+        }
         *reinterpret_cast<uint4 *>(&xt[vc * XCS + 4 * lane]) = make_uint4(u[0], u[1], u[2], u[3]);
-        // x = hi + mid + lo, each a bf16 (exact); inf / nan become 0 here and are added to their
-        // own key's cells by the counters (0 x inf would poison every key's cell)
-        unsigned hi[4], mi[4], lo[4];
-        bool nonfinite = false;
+        // x = hi + mid + lo, each a bf16 (exact): hi = upper half of x, mid = upper half of
+        // x - hi, lo = x - hi - mid (its lower half is zero).  v_perm_b32 packs the upper halves
+        // of two values into one dword.
+        constexpr unsigned UPPER_HALVES = 0x07060302u;      // {s0.b3, s0.b2, s1.b3, s1.b2}
+        float r1[4], r2[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const float x = __uint_as_float(u[e]);
-          const unsigned uh = u[e] & 0xFFFF0000u;
-          const float r1 = x - __uint_as_float(uh);
-          const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
-          const float r2 = r1 - __uint_as_float(um);
-          const bool fin = (u[e] & 0x7F800000u) != 0x7F800000u;
-          nonfinite = nonfinite || !fin;
-          hi[e] = fin ? uh >> 16 : 0u;
-          mi[e] = fin ? um >> 16 : 0u;
-          lo[e] = fin ? __float_as_uint(r2) >> 16 : 0u;
+          r1[e] = __uint_as_float(u[e]) - __uint_as_float(u[e] & 0xFFFF0000u);
+          r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xFFFF0000u);
         }
-        *reinterpret_cast<uint2 *>(&pt[vc * PTS + 4 * lane]) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-        *reinterpret_cast<uint2 *>(&pt[(n + vc) * PTS + 4 * lane]) = make_uint2(mi[0] | (mi[1] << 16), mi[2] | (mi[3] << 16));
-        *reinterpret_cast<uint2 *>(&pt[(2 * n + vc) * PTS + 4 * lane]) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        uint2 ph = make_uint2(__builtin_amdgcn_perm(u[1], u[0], UPPER_HALVES), __builtin_amdgcn_perm(u[3], u[2], UPPER_HALVES));
+        uint2 pm = make_uint2(__builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), UPPER_HALVES),
+                              __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), UPPER_HALVES));
+        uint2 pl = make_uint2(__builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), UPPER_HALVES),
+                              __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), UPPER_HALVES));
+        // inf / nan (rare): their pieces become 0 here and the value is added to its own key's
+        // cells by the counters (0 x inf would poison every key's cell)
+        constexpr int INF_NAN = 0x207;                      // sNaN | qNaN | -inf | +inf
+        const bool bad0 = __builtin_amdgcn_classf(__uint_as_float(u[0]), INF_NAN), bad1 = __builtin_amdgcn_classf(__uint_as_float(u[1]), INF_NAN);
+        const bool bad2 = __builtin_amdgcn_classf(__uint_as_float(u[2]), INF_NAN), bad3 = __builtin_amdgcn_classf(__uint_as_float(u[3]), INF_NAN);
+        const bool nonfinite = bad0 || bad1 || bad2 || bad3;
+        if (nonfinite) {
+          const unsigned k0 = (bad0 ? 0u : 0x0000FFFFu) | (bad1 ? 0u : 0xFFFF0000u);
+          const unsigned k1 = (bad2 ? 0u : 0x0000FFFFu) | (bad3 ? 0u : 0xFFFF0000u);
+          ph.x &= k0; pm.x &= k0; pl.x &= k0;
+          ph.y &= k1; pm.y &= k1; pl.y &= k1;
+        }
+        *reinterpret_cast<uint2 *>(&pt[vc * PTS + 4 * lane]) = ph;
+        *reinterpret_cast<uint2 *>(&pt[(n + vc) * PTS + 4 * lane]) = pm;
+        *reinterpret_cast<uint2 *>(&pt[(2 * n + vc) * PTS + 4 * lane]) = pl;
         if (nonfinite) l_nf[b] = stamp;                     // this tile holds inf / nan
       } else if (vc < n + m) {
         const int c = vc - n;
