@@ -349,7 +349,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
 #pragma unroll
     for (int c = 0; c < MC; c++)
       if (c < m) {
-        atomicAdd(&l_cnt[16 * c + cd[c]], 1u);
+        // counts: with two or more key columns they are row sums of a pair table and are taken
+        // from there by fused_pairs_fold_kernel (16 cells per column make these the most
+        // contended LDS atomics of the kernel); a single key column counts here
+        if (M == 1) atomicAdd(&l_cnt[16 * c + cd[c]], 1u);
         row8[c] = 32u * cd[c];                              // byte offset of the row in a pair table
         half[c] = lp_base + 4u * (cd[c] >> 1);              // LDS address of the dword inside row 0
         inc[c] = 1u << ((cd[c] & 1u) * 16u);
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       }
     partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
   }
-  for (int i = tid; i < L.n_cnt; i += FUSED_THREADS)
+  for (int i = tid; M == 1 && i < L.n_cnt; i += FUSED_THREADS)
     if (l_cnt[i]) {
       atomicAdd(&D.cnt[i], (unsigned long long)l_cnt[i]);
       const int c = i >> 4, code = i & 15;                  // cnt_off[c] = 16 c in the fused layout
@@ -556,14 +559,33 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
 }
 
 // D.p[cell] += sum over workgroups of slab[wg][cell]
+// With m >= 2 key columns the kernel keeps no count table: a column's counts are the row sums of
+// its pair table with the next column (column sums for the last column), added here to cnt and to
+// the diagonal cells (k, k) of the column's own pair table.  Fused layout: table q = 256 cells
+// [code1][code2], counts of column c at cnt[16 c ..].
 __global__ __launch_bounds__(256) void fused_pairs_fold_kernel(const unsigned *__restrict__ slabs, int nwg,
-                                                               int cells_padded, int n_p,
-                                                               unsigned long long *__restrict__ p) {
+                                                               int cells_padded, int n_p, int m,
+                                                               unsigned long long *__restrict__ p,
+                                                               unsigned long long *__restrict__ cnt) {
   const int cell = blockIdx.x * blockDim.x + threadIdx.x;
   if (cell >= n_p) return;
   unsigned long long total = 0;
   for (int w = 0; w < nwg; w++) total += slabs[(uint64_t)w * cells_padded + cell];
-  if (total) p[cell] += total;
+  if (!total) return;
+  p[cell] += total;
+  if (m < 2) return;
+  const int q = cell >> 8, k1 = (cell >> 4) & 15, k2 = cell & 15;
+  int c1 = 0, rem = q;
+  while (rem >= m - c1) { rem -= m - c1; c1++; }           // q = index of (c1, c1 + rem), c2 >= c1
+  if (rem != 1) return;                                     // only the tables (c, c + 1) carry counts
+  const int qd1 = c1 * m - c1 * (c1 - 1) / 2;              // index of pair (c1, c1)
+  atomicAdd(&cnt[16 * c1 + k1], total);
+  atomicAdd(&p[256 * qd1 + 17 * k1], total);
+  if (c1 + 1 == m - 1) {                                    // the last column has no successor
+    const int c2 = m - 1, qd2 = c2 * m - c2 * (c2 - 1) / 2;
+    atomicAdd(&cnt[16 * c2 + k2], total);
+    atomicAdd(&p[256 * qd2 + 17 * k2], total);
+  }
 }
 
 // temp[col][i * 256 + j] = col[list[i] * 256 + j]: the tiles the optimistic pass left out, packed
@@ -682,7 +704,7 @@ hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, c
   if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
   const int cells_padded = 2 * ((L.n_p + 1) / 2);
   hipLaunchKernelGGL(fused_pairs_fold_kernel, dim3((L.n_p + 255) / 256), dim3(256), 0, stream, pair_slabs,
-                     grid, cells_padded, L.n_p, D.p);
+                     grid, cells_padded, L.n_p, L.m, D.p, D.cnt);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return launch_gram_fold(partials, grid, acc, stream);
 }
