@@ -87,6 +87,7 @@ __device__ __forceinline__ uint2 lds_lookup4(const unsigned long long *slots, co
 // (hipcc scalarises 16-bit vector compares into v_cmp/v_cndmask/v_perm chains).
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 constexpr int DIRECT_KEYS = 256;        // keys 0..255 of a column are looked up in a byte table
+constexpr int DIRECT_STRIDE = 260;      // bytes per column: 256 keys + the NO_CODE entry every other key reads
 constexpr unsigned NO_CODE = 16u;
 constexpr unsigned ROW_OFF = 17u;   // code of every column of a row the row filter dropped (matches no i either)
 __device__ __forceinline__ bf16x8 onehot8(uint4 cv, unsigned ii) {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   unsigned *l_nf = reinterpret_cast<unsigned *>(lds + cv.nf);     // [buffer]: stamp of a tile holding inf / nan
   unsigned *l_skip = l_nf + 2;                                    // [buffer]: stamp of a tile with an unknown key
   unsigned char *l_direct = lds + cv.direct;                      // [column][key 0..255] -> code (NO_CODE if absent)
-  unsigned char *l_far = l_direct + M * DIRECT_KEYS;              // [column]: the dictionary holds a key outside 0..255
+  unsigned char *l_far = l_direct + M * DIRECT_STRIDE;              // [column]: the dictionary holds a key outside 0..255
   auto xt_of = [&](int b) { return reinterpret_cast<float *>(lds + cv.xt + b * cv.xt_stride); };
   auto pt_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.pt + b * cv.pt_stride); };
   auto codes_of = [&](int b) { return reinterpret_cast<unsigned short *>(lds + cv.codes + b * cv.codes_stride); };
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   // Small non-negative keys (the usual encoding of a categorical column) skip the hash probe: a
   // byte table per column maps key 0..255 to its code.  A column whose dictionary holds any
   // other key keeps probing (flag per column).
-  for (int i = tid; i < M * DIRECT_KEYS; i += FUSED_THREADS) l_direct[i] = (unsigned char)NO_CODE;
+  for (int i = tid; i < M * DIRECT_STRIDE; i += FUSED_THREADS) l_direct[i] = (unsigned char)NO_CODE;
   if (tid < 32) l_far[tid] = 0;
   __syncthreads();
   for (int c = 0; c < m; c++)
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       const int32_t cdv = l_dcode[L.ht_off[c] + i];
       if (sv != 0ull && cdv >= 0) {
         const unsigned key = (unsigned)(sv & 0xFFFFFFFFull);
-        if (key < (unsigned)DIRECT_KEYS) l_direct[c * DIRECT_KEYS + key] = (unsigned char)cdv;
+        if (key < (unsigned)DIRECT_KEYS) l_direct[c * DIRECT_STRIDE + key] = (unsigned char)cdv;
         else l_far[c] = 1;
       }
     }
@@ -291,10 +292,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
         uint2 packed;
         if (ablate & 8) packed = make_uint2((pre[i].x & 15u) | ((pre[i].y & 15u) << 16), (pre[i].z & 15u) | ((pre[i].w & 15u) << 16));
         else if (!l_far[c]) {                               // wave-uniform: byte table
-          const unsigned char *dt = l_direct + c * DIRECT_KEYS;
-          const unsigned kx = pre[i].x, ky = pre[i].y, kz = pre[i].z, kw = pre[i].w;
-          const unsigned cx = kx < (unsigned)DIRECT_KEYS ? dt[kx] : NO_CODE, cy = ky < (unsigned)DIRECT_KEYS ? dt[ky] : NO_CODE;
-          const unsigned cz = kz < (unsigned)DIRECT_KEYS ? dt[kz] : NO_CODE, cw = kw < (unsigned)DIRECT_KEYS ? dt[kw] : NO_CODE;
+          const unsigned char *dt = l_direct + c * DIRECT_STRIDE;
+          // any key outside 0..255 (negative ones are huge as unsigned) reads entry 256 = NO_CODE
+          const unsigned cx = dt[min(pre[i].x, (unsigned)DIRECT_KEYS)], cy = dt[min(pre[i].y, (unsigned)DIRECT_KEYS)];
+          const unsigned cz = dt[min(pre[i].z, (unsigned)DIRECT_KEYS)], cw = dt[min(pre[i].w, (unsigned)DIRECT_KEYS)];
           packed = make_uint2(cx | (cy << 16), cz | (cw << 16));
         } else packed = lds_lookup4(slots, dc, cap, pre[i]);
         *reinterpret_cast<uint2 *>(&codes[c * PTS + 4 * lane]) = packed;
@@ -624,7 +625,7 @@ FusedCarve make_carve(const CatLayout &L, int nb) {
   c.pairs = take((size_t)((L.n_p + 1) / 2) * 4, 4);
   c.nf = take(16, 4);
   c.gsum = take(sizeof(double) * 4 * GRAM_ACC_LEN, 8);
-  c.direct = take((size_t)L.m * DIRECT_KEYS + 32, 4);     // per key column: code of key 0..255, then the flags
+  c.direct = take((size_t)L.m * DIRECT_STRIDE + 32, 4);     // per key column: code of key 0..255, then the flags
   c.total = (int)((o + 15) / 16 * 16);
   return c;
 }
