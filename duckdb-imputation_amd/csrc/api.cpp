@@ -254,7 +254,7 @@ void plan_cat_passes(const CatLayout &L, size_t lds_budget, std::vector<CatPass>
   lds_passes.clear();
   hbm_needed = false;
   hbm_pass = CatPass{};
-  const size_t dict = (size_t)L.n_slots * 12;
+  const size_t dict = (size_t)L.n_slots * 12 + cat_direct_lds_bytes(L.m);   // dictionaries + byte-key tables
   const bool dict_lds = dict <= lds_budget / 2;
   const size_t budget = dict_lds ? lds_budget - dict : lds_budget;
   hbm_pass.dict_lds = dict_lds && dict <= 48 * 1024;

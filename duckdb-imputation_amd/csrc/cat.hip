@@ -200,15 +200,34 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
   int32_t *l_code = reinterpret_cast<int32_t *>(l_s + t_s);
   unsigned *l_cnt = reinterpret_cast<unsigned *>(l_code + d_slots);
   unsigned *l_p = l_cnt + t_cnt;
+  unsigned short *l_direct = reinterpret_cast<unsigned short *>(l_p + t_p);   // [column][key 0..255 | other] -> code
   constexpr int MC = MT > 0 ? MT : COFACTOR_MAX_CAT;       // unroll bound
   const int m = MT > 0 ? MT : L.m;
+  unsigned char *l_far = reinterpret_cast<unsigned char *>(l_direct + m * CAT_DIRECT_STRIDE);   // [column]: a key outside 0..255
 
   const int tid = threadIdx.x;
   for (int i = tid; i < d_slots; i += CAT_THREADS) { l_slot[i] = D.ht_slot[i]; l_code[i] = D.ht_code[i]; }
   for (int i = tid; i < t_cnt; i += CAT_THREADS) l_cnt[i] = 0u;
   for (int i = tid; i < t_s; i += CAT_THREADS) l_s[i] = 0.0;
   for (int i = tid; i < t_p; i += CAT_THREADS) l_p[i] = 0u;
+  if (P.dict_lds) {
+    for (int i = tid; i < m * CAT_DIRECT_STRIDE; i += CAT_THREADS) l_direct[i] = 0xFFFFu;
+    if (tid < 32) l_far[tid] = 0;
+  }
   __syncthreads();
+  if (P.dict_lds) {
+    for (int c = 0; c < m; c++)
+      for (int i = tid; i < L.ht_cap[c]; i += CAT_THREADS) {
+        const unsigned long long sv = l_slot[L.ht_off[c] + i];
+        const int32_t cdv = l_code[L.ht_off[c] + i];
+        if (sv != 0ull && cdv >= 0) {
+          const unsigned key = (unsigned)(sv & 0xFFFFFFFFull);
+          if (key < (unsigned)CAT_DIRECT_KEYS && cdv < 0xFFFF) l_direct[c * CAT_DIRECT_STRIDE + key] = (unsigned short)cdv;
+          else l_far[c] = 1;
+        }
+      }
+    __syncthreads();
+  }
   // dictionary through generic pointers: LDS copy when it fits, HBM otherwise
   const unsigned long long *dict_slot = P.dict_lds ? l_slot : D.ht_slot;
   const int32_t *dict_code = P.dict_lds ? l_code : D.ht_code;
@@ -233,7 +252,12 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_accumulate_kernel(NumCols num
 #pragma unroll
     for (int c = 0; c < MC; c++) {
       if (c < m && ((P.col_mask >> c) & 1u)) {
-        code[c] = lookup_code(dict_slot + L.ht_off[c], dict_code + L.ht_off[c], L.ht_cap[c], key[c]);
+        if (P.dict_lds && !l_far[c]) {                      // keys 0..255: one table read
+          const unsigned e = l_direct[c * CAT_DIRECT_STRIDE + min((unsigned)key[c], (unsigned)CAT_DIRECT_KEYS)];
+          code[c] = e == 0xFFFFu ? -1 : (int)e;
+        } else {
+          code[c] = lookup_code(dict_slot + L.ht_off[c], dict_code + L.ht_off[c], L.ht_cap[c], key[c]);
+        }
         known = known && code[c] >= 0 && code[c] < L.kc[c];
       }
     }
@@ -326,7 +350,7 @@ hipError_t launch_acc_m(int m, const NumCols &num, const CatCols &cat, uint64_t 
 }  // namespace
 
 size_t cat_pass_lds_bytes(const CatLayout &L, const CatPass &P, bool lds_tables) {
-  size_t b = P.dict_lds ? (size_t)L.n_slots * (8 + 4) : 0;
+  size_t b = P.dict_lds ? (size_t)L.n_slots * (8 + 4) + cat_direct_lds_bytes(L.m) : 0;
   if (lds_tables) {
     if (P.do_cnt) b += (size_t)L.n_cnt * 4;
     if (L.kind == 0 && P.do_s) b += (size_t)L.n_s * 8;

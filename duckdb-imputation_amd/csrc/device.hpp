@@ -82,6 +82,12 @@ struct CatPass {
   int p_base, p_cells;                        // LDS pair tables cover cells [p_base, p_base + p_cells)
   int dict_lds;                               // dictionaries are copied to LDS
 };
+// Keys 0..255 of a column (the usual encoding of a categorical column) skip the hash probe: next to
+// the LDS copy of the dictionaries sits a u16 table per column, key -> code, with one more entry
+// that every other key reads (0xFFFF = not in the table).
+constexpr int CAT_DIRECT_KEYS = 256;
+constexpr int CAT_DIRECT_STRIDE = 260;            // u16 entries per column
+inline size_t cat_direct_lds_bytes(int m) { return (size_t)m * CAT_DIRECT_STRIDE * 2 + 32; }
 size_t cat_pass_lds_bytes(const CatLayout &L, const CatPass &P, bool lds_tables);
 
 hipError_t launch_cat_insert(const CatCols &cols, uint64_t rows, const CatLayout &L,
