@@ -41,7 +41,9 @@ namespace {
 constexpr int TR = GRAM_TILE_ROWS;      // 256 rows per tile, one thread per row
 constexpr int XCS = GRAM_COL_STRIDE;    // float stride of an xt column
 constexpr int PTS = TR + 8;             // u16 stride of a codes column (528 B, 16-B aligned)
-constexpr int S_FLUSH_TILES = 8;
+constexpr int S_FLUSH_TILES = 32;        // tiles between fp64 folds of the per-key sums: a cell then holds at most
+                                        // 2048 fp32 adds of bf16 pieces (8-bit mantissas, so mostly exact); measured
+                                        // error with ONE key per column <= 4e-8 (tests/tools/s_error_probe.py)
 constexpr int G_FLUSH_TILES = 4;
 constexpr int LOAD_RING = 2;            // tiles whose loads the loader team keeps in flight
 constexpr int P_FLUSH_TILES = 240;      // 240 * 256 rows < 65536: a 16-bit pair cell cannot wrap

@@ -385,6 +385,31 @@ def test_masked_update_with_a_filter_that_is_not_word_aligned(ctx, n, m, shift):
     agg.close()
 
 
+def test_fused_per_key_sums_with_a_single_key_stay_far_inside_the_tolerance(ctx):
+    """The fused kernel keeps per-key partial sums in fp32 MFMA accumulators between fp64 folds;
+    the longest fp32 chains arise when a column has ONE key (every row lands in the same cell).
+    Heavy-tailed values, 4 M rows: the sums must still be within 1e-6 of the fp64 sums, an order of
+    magnitude inside the 1e-5 the path promises."""
+    import torch
+    rows, n, m = 4_000_000, 10, 10
+    g = torch.Generator(device="cuda").manual_seed(3)
+    num = [torch.exp(3 * torch.randn(rows, generator=g, device="cuda")).contiguous() for _ in range(n)]
+    cat = [torch.full((rows,), 7 + c, dtype=torch.int32, device="cuda") for c in range(m)]
+    agg = ctx.aggregate(n, m)
+    ctx.profile(True); ctx.profile_read()
+    agg.update_device(num, cat)
+    t = blob_to_dict(agg.finalize())
+    prof = ctx.profile_read(); ctx.profile(False)
+    agg.close()
+    assert prof["fused_launches"] >= 1
+    for k in range(n):
+        want = float(num[k].double().sum())
+        for c in (0, 4, 9):
+            (entry,) = t["quad_num_cat"][k * m + c]
+            assert entry["key"] == 7 + c
+            assert abs(entry["value"] - want) <= 1e-6 * want, (k, c)
+
+
 def test_nb_aggregate(ctx):
     rng = np.random.default_rng(21)
     rows = 30_000
