@@ -44,7 +44,7 @@ constexpr int PTS = TR + 8;             // u16 stride of a codes column (528 B, 
 constexpr int S_FLUSH_TILES = 32;        // tiles between fp64 folds of the per-key sums: a cell then holds at most
                                         // 2048 fp32 adds of bf16 pieces (8-bit mantissas, so mostly exact); measured
                                         // error with ONE key per column <= 4e-8 (tests/tools/s_error_probe.py)
-constexpr int G_FLUSH_TILES = 4;
+constexpr int G_FLUSH_TILES = 4;        // x rows per MFMA: at most 64 fp32 adds per Gram chain between fp64 folds
 constexpr int LOAD_RING = 2;            // tiles whose loads the loader team keeps in flight
 constexpr int P_FLUSH_TILES = 240;      // 240 * 256 rows < 65536: a 16-bit pair cell cannot wrap
 
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     unsigned k = 1;
     for (uint64_t t = blockIdx.x; t < ntiles; t += G, k++) {
       if (l_skip[b] != k) crunch(b);
-      if (++since_g == G_FLUSH_TILES) { flush_gram(); since_g = 0; }
+      if (++since_g == G_FLUSH_TILES * RPM) { flush_gram(); since_g = 0; }
       if (++since_s == S_FLUSH_TILES) { flush_s(); since_s = 0; }
       __syncthreads();
       b ^= 1;
