@@ -268,3 +268,38 @@ def test_predict_rejects_a_parameter_vector_of_another_shape():
     with pytest.raises(cofactor_hip.CofactorError):
         ctx.linreg_predict(params, tn, tc, noise=True)     # trained without variance
     ctx.close()
+
+
+# ---- edge cases of the trainers (CPU) ---------------------------------------------------------------
+
+def test_trainers_on_degenerate_triples():
+    """no key columns at all, one class only, a label that is not a column: clean errors or finite
+    parameter vectors, never a crash (the reference asserts or reads out of bounds here)."""
+    rng = np.random.default_rng(1)
+    x = [rng.normal(size=50).astype(np.float32) for _ in range(3)]
+    only_num = oracle.State(oracle.WIDE).update(x, []).finalize()
+    p = cofactor_hip.linreg_train(only_num, 2, 0.001, 0.0, 500, True, False)
+    assert p[0] == 0 and len(p) == 1 + 3 + 1 and np.all(np.isfinite(p))      # m, intercept + 2 coefs, std
+    with pytest.raises(cofactor_hip.CofactorError):
+        cofactor_hip.lda_train(only_num, 0)                                   # no key column to classify
+    one_class = oracle.State(oracle.WIDE).update(x, [np.full(50, 4, dtype=np.int32)]).finalize()
+    q = cofactor_hip.lda_train(one_class, 0, 0.1, False)
+    assert q[0] == 1 and q[2] == 4 and np.all(np.isfinite(q))                 # one class, its key
+    with pytest.raises(cofactor_hip.CofactorError):
+        cofactor_hip.lda_train(one_class, 1)
+    with pytest.raises(cofactor_hip.CofactorError):
+        cofactor_hip.linreg_train(np.zeros(3), 0)                             # not a triple blob
+
+
+def test_linreg_gradient_descent_reaches_the_normal_equations():
+    """the reference's descent, run long enough on a well-conditioned problem, solves X^T X w = X^T y"""
+    rng = np.random.default_rng(2)
+    rows = 400
+    x1, x2 = rng.normal(size=rows), rng.normal(size=rows)
+    y = 1.5 + 2.0 * x1 - 0.5 * x2 + 0.05 * rng.normal(size=rows)
+    cols = [c.astype(np.float32) for c in (y, x1, x2)]
+    blob = oracle.State(oracle.WIDE).update(cols, []).finalize()
+    p = cofactor_hip.linreg_train(blob, 0, 0.001, 0.0, 10000, False, False)
+    X = np.stack([np.ones(rows), cols[1].astype(np.float64), cols[2].astype(np.float64)], 1)
+    w = np.linalg.lstsq(X, cols[0].astype(np.float64), rcond=None)[0]
+    assert np.allclose(p[1:], w, rtol=1e-3, atol=1e-3)
