@@ -46,7 +46,6 @@ constexpr int S_FLUSH_TILES = 32;        // tiles between fp64 folds of the per-
                                         // error with ONE key per column <= 4e-8 (tests/tools/s_error_probe.py)
 constexpr int G_FLUSH_TILES = 4;        // x rows per MFMA: at most 64 fp32 adds per Gram chain between fp64 folds
 constexpr int LOAD_RING = 2;            // tiles whose loads the loader team keeps in flight
-constexpr int P_FLUSH_TILES = 240;      // 240 * 256 rows < 65536: a 16-bit pair cell cannot wrap
 
 __device__ __forceinline__ unsigned fhash(int32_t key, int cap) {
   return ((unsigned)key * 0x9E3779B1u) >> (32 - (31 - __builtin_clz(cap)));
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   const int tt = tid & (TEAM - 1);                         // thread index inside its team
   const int n = L.n;
   constexpr int m = M;
-  const int n_pw = (L.n_p + 1) / 2;                        // dwords of the packed pair table
+  const int n_pw = L.n_p;                                  // dwords of the pair tables (one u32 cell each)
 
   // ---- one-time LDS setup ------------------------------------------------------------------
   for (int b = 0; b < 2; b++) {
@@ -315,20 +314,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
       }
     }
   };
-  // packed 16-bit pair cells -> this workgroup's private u32 slab in HBM (first time: store).
-  // Loader team only; atomicExch makes read-and-clear safe against increments that run ahead.
-  unsigned *slab = pair_slabs + (uint64_t)blockIdx.x * (uint64_t)(2 * n_pw);
-  bool slab_fresh = true;
+  // pair cells -> this workgroup's private u32 slab in HBM, once at the end (a u32 cell holds the
+  // rows of any launch).  atomicExch makes read-and-clear safe against increments that run ahead.
+  unsigned *slab = pair_slabs + (uint64_t)blockIdx.x * (uint64_t)n_pw;
   auto flush_pairs = [&]() {
-    for (int w = tt; w < n_pw; w += TEAM) {
-      const unsigned v = atomicExch(&l_p[w], 0u);
-      uint2 *dst = reinterpret_cast<uint2 *>(slab + 2 * w);
-      uint2 cur = slab_fresh ? make_uint2(0u, 0u) : *dst;
-      cur.x += v & 0xFFFFu;
-      cur.y += v >> 16;
-      *dst = cur;
-    }
-    slab_fresh = false;
+    for (int w = tt; w < n_pw; w += TEAM) slab[w] = atomicExch(&l_p[w], 0u);
   };
   // counts and pair counts of tile t (buffer b), one loader thread per row
   unsigned n_kept = 0;                                     // rows this counter thread counted (masked updates)
@@ -344,11 +334,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     n_kept++;
     if (!known) { D.flags[1] = 1; return; }                 // surfaces as an error at finalize
     // every column has code capacity 16 here (fused_applicable), so pair table q starts at cell
-    // 256 q and cell = 256 q + 16 code1 + code2: dword 128 q + 8 code1 + (code2 >> 1), upper half
-    // when code2 is odd.  Diagonal pairs (c, c) only ever hit cells (k, k) with the column's own
-    // counts: they are filled from the count table at the end instead.
+    // 256 q and cell = 256 q + 16 code1 + code2, one dword each (16-bit cells packed two per
+    // dword halve the table but double the lanes that collide on a dword).  Diagonal pairs
+    // (c, c) only ever hit cells (k, k) with the column's own counts: the fold kernel fills them.
     const unsigned lp_base = (unsigned)(unsigned long long)(lds_u32 *)l_p;   // 32-bit LDS address
-    unsigned row8[MC], half[MC], inc[MC];
+    unsigned row8[MC], half[MC];
 #pragma unroll
     for (int c = 0; c < MC; c++)
       if (c < m) {
@@ -356,12 +346,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
         // from there by fused_pairs_fold_kernel (16 cells per column make these the most
         // contended LDS atomics of the kernel); a single key column counts here
         if (M == 1) atomicAdd(&l_cnt[16 * c + cd[c]], 1u);
-        row8[c] = 32u * cd[c];                              // byte offset of the row in a pair table
-        half[c] = lp_base + 4u * (cd[c] >> 1);              // LDS address of the dword inside row 0
-        inc[c] = 1u << ((cd[c] & 1u) * 16u);
-        // keep the three in registers: left alone the compiler recomputes them from the code
-        // for every one of the m(m-1)/2 pairs (5 VALU per pair instead of 1)
-        asm volatile("" : "+v"(row8[c]), "+v"(half[c]), "+v"(inc[c]));
+        row8[c] = 64u * cd[c];                              // byte offset of the row in a pair table
+        half[c] = lp_base + 4u * cd[c];                     // LDS address of the cell inside row 0
+        // keep the two in registers: left alone the compiler recomputes them from the code for
+        // every one of the m(m-1)/2 pairs
+        asm volatile("" : "+v"(row8[c]), "+v"(half[c]));
       }
     int q = 0;
 #pragma unroll
@@ -369,9 +358,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
 #pragma unroll
       for (int c2 = c1; c2 < MC; c2++)
         if (c2 < m) {
-          if (c2 != c1)                                     // one v_add + ds_add_u32 offset:512q
-            __hip_atomic_fetch_add((lds_u32 *)(unsigned long long)(row8[c1] + half[c2] + 512u * q),
-                                   inc[c2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (c2 != c1)                                     // one v_add + ds_add_u32 offset:1024q
+            __hip_atomic_fetch_add((lds_u32 *)(unsigned long long)(row8[c1] + half[c2] + 1024u * q),
+                                   1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           q++;
         }
     if (l_nf[b] == stamp) {                                 // rare: pieces8 fed 0 for inf / nan
@@ -503,16 +492,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
     }
   } else if (team == 1) {
     __syncthreads();
-    int b = 0, since_p = 0;
+    int b = 0;
     unsigned k = 1;
     for (uint64_t t = blockIdx.x; t < ntiles; t += G) {
-      if (since_p == P_FLUSH_TILES) { flush_pairs(); since_p = 0; }
       if (l_skip[b] == k) {                                 // tile left out: remember it for the host
         if (tt == 0) skip[1 + atomicAdd(&skip[0], 1u)] = (unsigned)t;
       } else {
         count_rows(b, k);
       }
-      since_p++;
       __syncthreads();
       b ^= 1; k++;
     }
@@ -624,7 +611,7 @@ FusedCarve make_carve(const CatLayout &L, int nb) {
   c.slot = take((size_t)L.n_slots * 8, 8);
   c.dcode = take((size_t)L.n_slots * 4, 4);
   c.cnt = take((size_t)L.n_cnt * 4, 4);
-  c.pairs = take((size_t)((L.n_p + 1) / 2) * 4, 4);
+  c.pairs = take((size_t)L.n_p * 4, 4);
   c.nf = take(16, 4);
   c.gsum = take(sizeof(double) * 4 * GRAM_ACC_LEN, 8);
   c.direct = take((size_t)L.m * DIRECT_STRIDE + 32, 4);     // per key column: code of key 0..255, then the flags
@@ -684,7 +671,7 @@ int fused_grid(const CatLayout &L, int cus, int partials_cap_wgs, uint64_t rows)
 }
 
 size_t fused_slab_bytes(const CatLayout &L, int grid) {
-  return (size_t)grid * (size_t)(2 * ((L.n_p + 1) / 2)) * sizeof(unsigned);
+  return (size_t)grid * (size_t)L.n_p * sizeof(unsigned);
 }
 
 hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
@@ -705,7 +692,7 @@ hipError_t launch_fused(const NumCols &num, const CatCols &cat, uint64_t rows, c
 #undef GO
   if (e != hipSuccess) return e;
   if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
-  const int cells_padded = 2 * ((L.n_p + 1) / 2);
+  const int cells_padded = L.n_p;
   hipLaunchKernelGGL(fused_pairs_fold_kernel, dim3((L.n_p + 255) / 256), dim3(256), 0, stream, pair_slabs,
                      grid, cells_padded, L.n_p, L.m, D.p, D.cnt);
   if ((e = hipGetLastError()) != hipSuccess) return e;
