@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — rows/s of sum_to_triple_20_0 on MI355X (BASELINE.json metric), one process per GPU.
+"""bench.py — rows/s of sum_to_triple_20_0 over 1e9 rows on MI355X (BASELINE.json's metric), one
+process per GPU.
 
-A "step" is one complete pass of the hot path over the rank's resident table: reset the
-aggregate, cofactor_agg_update_device over all rows (HIP Gram kernel), for N > 1 one RCCL
-all-reduce of the dense partial triple, and finalize to the host blob.  Inputs are synthetic
-(uniform [0,1) float32 columns, seed 42) and already resident in HBM when the timed region starts.
+A "step" is one complete pass of the hot path over the resident table: reset the aggregate,
+cofactor_agg_update_device over the rank's rows (HIP kernels), for N > 1 ONE RCCL all-reduce of the
+partial triple (export kernel -> all-reduce -> import kernel on the library's stream), and
+finalize to the host blob.  Inputs are synthetic (cofactor_hip/synth.py: counter-based generator,
+seed 42, uniform [0,1) float32 columns, so that every sharding is the SAME table) and already
+resident in HBM when the timed region starts.
 
-    python bench.py                       # N = 1, 1e9 rows x 20 float columns (80 GB in HBM)
+    python bench.py                       # N = 1: 1e9 rows x 20 float columns (80 GB in HBM)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Weak scaling: every rank holds `--rows` rows (default 1e9), the table has N * rows rows.
-Rank 0 prints ONE JSON line.
+N > 1 is BASELINE.json's configs[3] — the SAME 1e9-row table sharded over the ranks ("scaling":
+"strong"); `--scaling weak` gives every rank `--rows` rows instead.  After the timed loop the
+reduced triple is checked against torch fp64 reductions of the same columns (all column sums and
+a sample of the products, summed over the ranks) and its checksum is printed, so the runs at
+N = 1, 2, 4, 8 can be compared value for value.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -25,6 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "duckdb-imputation_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SEED = 42
 
 
 def parse():
@@ -32,44 +39,101 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU")
+    ap.add_argument("--total-rows", type=float, default=1e9, help="rows of the whole table (strong scaling)")
+    ap.add_argument("--rows", type=float, default=None, help="rows per GPU (implies --scaling weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None)
     ap.add_argument("--num-cols", type=int, default=20)
     ap.add_argument("--cat-cols", type=int, default=0)
     ap.add_argument("--keys", type=int, default=16, help="distinct keys per categorical column")
+    ap.add_argument("--nb", action="store_true", help="sum_to_nb_agg instead of sum_to_triple")
     ap.add_argument("--cpu-sample-rows", type=float, default=6e7)
+    ap.add_argument("--cpu-1t-sample-rows", type=float, default=2e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--rehearse-dist", action="store_true", help="run the multi-GPU code path at the current world size")
     return ap.parse_args()
 
 
-def make_table(torch, rows, n, m, keys, device, seed):
-    g = torch.Generator(device=device).manual_seed(seed)
-    num = [torch.rand(rows, generator=g, device=device, dtype=torch.float32) for _ in range(n)]
-    cat = [torch.randint(0, keys, (rows,), generator=g, device=device, dtype=torch.int32) for _ in range(m)]
-    return num, cat
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(torch, num, cat, sample_rows, n, m):
+def cpu_baseline(num, cat, rows_mt, rows_1t, n, m, nb):
     """The oracle in faithful (float accumulator) mode — a port of the reference's update loop,
-    std::map categoricals included — on a bounded prefix of the same table, thread-local states
-    over contiguous shards merged by combine, as DuckDB runs the reference."""
+    std::map categoricals included (kind "port": the reference itself needs DuckDB headers that are
+    not in the image) — on a bounded prefix of the same table: (i) one thread, (ii) one thread per
+    host core with thread-local states over contiguous shards merged by combine, as DuckDB runs
+    the reference."""
     from oracle import oracle as orc
-    rows = int(min(sample_rows, num[0].numel() if num else cat[0].numel()))
-    h_num = [c[:rows].cpu().numpy() for c in num]
-    h_cat = [c[:rows].cpu().numpy() for c in cat]
+    have = num[0].numel() if num else cat[0].numel()
+    rows_mt, rows_1t = int(min(rows_mt, have)), int(min(rows_1t, have))
+    h_num = [c[:rows_mt].cpu().numpy() for c in num]
+    h_cat = [c[:rows_mt].cpu().numpy() for c in cat]
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    st = orc.State(orc.FAITHFUL)
+    cores = max(1, cores)
     t0 = time.perf_counter()
-    st.update(h_num, h_cat, threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": rows / dt, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": "first %d rows of the bench table, sum_to_triple_%d_%d, oracle faithful-fp32 "
-                      "mode, %d threads (thread-local states + combine), %.2f s wall"
-                      % (rows, n, m, cores, dt)}
+    orc.State(orc.FAITHFUL).update([c[:rows_1t] for c in h_num], [c[:rows_1t] for c in h_cat], nb=nb)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.State(orc.FAITHFUL).update(h_num, h_cat, nb=nb, threads=cores)
+    dtm = time.perf_counter() - t0
+    name = "sum_to_%s_%d_%d" % ("nb_agg" if nb else "triple", n, m)
+    return {"value": rows_mt / dtm, "unit": "rows/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(),
+            "one_thread": {"value": rows_1t / dt1, "unit": "rows/s", "cores": 1,
+                           "sample": "first %d rows, %.2f s wall" % (rows_1t, dt1)},
+            "sample": "first %d rows of the bench table, %s, oracle (CPU restatement of the reference's "
+                      "update loop) in faithful-fp32 mode, %d threads (thread-local states + combine), "
+                      "%.2f s wall" % (rows_mt, name, cores, dtm)}
+
+
+def calibrate(torch, device):
+    """What a plain streaming kernel reaches on this GPU: a 4 GiB float4 copy (read + write bytes)
+    and a read-only reduction, both torch built-ins, timed with events."""
+    words = 1 << 30
+    src = torch.empty(words, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    out = {}
+    for name, fn, nbytes in (("copy", lambda: dst.copy_(src), 8 * words), ("read", lambda: src.sum(), 4 * words)):
+        fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        out[name] = nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    torch.cuda.empty_cache()
+    return out
+
+
+def reference_sums(torch, num, pairs):
+    """fp64 column sums and the listed products of this rank's rows, by torch (chunked so the fp64
+    copies stay small)."""
+    n = len(num)
+    lin = torch.zeros(n, dtype=torch.float64, device=num[0].device)
+    quad = torch.zeros(len(pairs), dtype=torch.float64, device=num[0].device)
+    rows = num[0].numel()
+    step = 1 << 26
+    for a in range(0, rows, step):
+        d = [c[a:a + step].double() for c in num]
+        for k in range(n):
+            lin[k] += d[k].sum()
+        for i, (j, k) in enumerate(pairs):
+            quad[i] += torch.dot(d[j], d[k])
+    return lin, quad
 
 
 def main():
@@ -79,13 +143,14 @@ def main():
 
     import cofactor_hip
     from cofactor_hip import dist as cdist
+    from cofactor_hip import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+        sys.exit("bench.py --gpus %d needs WORLD_SIZE=%d (got %d): launch it with torch.distributed.run "
+                 "--nproc-per-node %d" % (args.gpus, args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # --rehearse-dist: take the N > 1 code path (RCCL process group, all-reduce of the partial
@@ -98,10 +163,17 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
-    rows, n, m = int(args.rows), args.num_cols, args.cat_cols
-    num, cat = make_table(torch, rows, n, m, args.keys, device, seed=42 + rank)
+    scaling = args.scaling or ("weak" if args.rows is not None else "strong")
+    if scaling == "weak":
+        per_gpu = int(args.rows if args.rows is not None else args.total_rows)
+        total_rows = per_gpu * world
+    else:
+        total_rows = int(args.total_rows)
+    lo, hi = cdist.shard_bounds(total_rows, rank, world)     # rank r holds rows [lo, hi) of ONE table
+    rows, n, m = hi - lo, args.num_cols, args.cat_cols
+    num, cat = synth.table(torch, SEED, n, m, lo, hi, device, keys=args.keys)
     ctx = cofactor_hip.Context(local_rank)
-    agg = ctx.aggregate(n, m)
+    agg = ctx.aggregate(n, m, cofactor_hip.NB if args.nb else cofactor_hip.TRIPLE)
     num_ptrs = [t.data_ptr() for t in num]
     cat_ptrs = [t.data_ptr() for t in cat]
     torch.cuda.synchronize()
@@ -110,8 +182,7 @@ def main():
         agg.reset()
         agg.update_device_ptrs(num_ptrs, cat_ptrs, rows)
         if use_dist:
-            # ONE RCCL all-reduce of the dense partial triple (+ host merge of categorical lists)
-            return cdist.allreduce_triple(agg, dist, device)
+            return cdist.allreduce_triple(agg, dist, device)     # ONE RCCL all-reduce, then finalize
         return agg.finalize()
 
     def fence():
@@ -139,9 +210,34 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    total_rows = rows * world
-    assert int(blob[3]) == total_rows, (blob[3], total_rows)      # N of the reduced triple
     value = total_rows * args.steps / dt
+
+    # ---- value check (outside the timed region): the reduced triple against torch fp64 sums ----
+    check = None
+    assert int(blob[3]) == total_rows, (blob[3], total_rows)          # N of the reduced triple
+    if n and not args.no_check:
+        pairs = [(j, j) for j in range(n)] + [(j, (j + 1 + j % 3) % n) for j in range(n) if n > 1]
+        pairs = [(min(j, k), max(j, k)) for j, k in pairs]
+        lin_ref, quad_ref = reference_sums(torch, num, pairs)
+        if use_dist:
+            dist.all_reduce(lin_ref)
+            dist.all_reduce(quad_ref)
+        lin_ref, quad_ref = lin_ref.cpu().numpy(), quad_ref.cpu().numpy()
+        lin = blob[4:4 + n]
+        qbase = 4 + n
+        if args.nb:
+            pairs_chk = [(i, p) for i, p in enumerate(pairs) if p[0] == p[1]]
+            qidx = lambda j, k: j
+        else:
+            pairs_chk = list(enumerate(pairs))
+            qidx = lambda j, k: j * n - j * (j - 1) // 2 + (k - j)
+        worst = max(abs(lin[k] - lin_ref[k]) / abs(lin_ref[k]) for k in range(n))
+        for i, (j, k) in pairs_chk:
+            worst = max(worst, abs(blob[qbase + qidx(j, k)] - quad_ref[i]) / abs(quad_ref[i]))
+        assert worst < 1e-6, "reduced triple differs from the fp64 reference by %.3g relative" % worst
+        check = {"N": int(blob[3]), "lin0": float(lin[0]), "quad00": float(blob[qbase]),
+                 "max_rel_err_vs_torch_fp64": worst, "entries_checked": n + len(pairs_chk),
+                 "lin_over_N": float(lin[0] / blob[3]), "quad00_over_N": float(blob[qbase] / blob[3])}
 
     if rank == 0:
         bytes_per_row = 4 * (n + m)
@@ -162,25 +258,36 @@ def main():
                     traffic = tj.get(key)
             except Exception:
                 traffic = None
+        fname = "sum_to_%s_%d_%d" % ("nb_agg" if args.nb else "triple", n, m)
+        roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_kernel_ms": avg_ms, "launches": kl, "algorithmic_bytes_per_launch": kbytes}
+        if not args.no_calibration:
+            cal = calibrate(torch, device)
+            roof["calibrated"] = {"copy_GBs": cal["copy"], "read_GBs": cal["read"],
+                                  "frac_of_copy": achieved / cal["copy"], "frac_of_read": achieved / cal["read"],
+                                  "how": "torch float32 copy_ (read + write bytes) and sum() (read bytes) over 4 GiB, "
+                                         "5 repetitions between events"}
         out = {
-            "metric": "rows/sec on sum_to_triple_%d_%d" % (n, m),
+            "metric": "rows/sec on %s" % fname,
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "sum_to_triple_%d_%d over %d rows per GPU (%d total), uniform[0,1) "
-                                   "float32 columns%s, resident in HBM" %
-                                   (n, m, rows, total_rows, (", %d int32 columns with %d keys" % (m, args.keys)) if m else ""),
-                       "rows_per_gpu": rows, "num_cols": n, "cat_cols": m,
-                       "arithmetic": "f32 inputs and MFMA products, f64 accumulation, exact integer counts",
-                       "parallelism": "row-sharded x%d, one RCCL all-reduce of the dense partial triple" % world},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_kernel_ms": avg_ms, "launches": kl,
-                         "algorithmic_bytes_per_launch": kbytes},
+            "config": {"workload": "%s over %d rows (%d per GPU, rank r = rows [r R/G, (r+1) R/G) of one seed-%d "
+                                   "table), uniform[0,1) float32 columns%s, resident in HBM" %
+                                   (fname, total_rows, rows, SEED,
+                                    (", %d int32 columns with %d keys" % (m, args.keys)) if m else ""),
+                       "total_rows": total_rows, "rows_per_gpu": rows, "num_cols": n, "cat_cols": m,
+                       "arithmetic": "f32 inputs and f32 MFMA products; f32 partial sums of at most 64 terms "
+                                     "(dense) / 2048 bf16-piece terms (per-key sums) folded into f64; exact "
+                                     "integer counts",
+                       "parallelism": "row-sharded x%d, one RCCL all-reduce of the partial triple" % world},
+            "roofline": roof,
+            "check": check,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(torch, num, cat, args.cpu_sample_rows, n, m)
+            out["cpu_baseline"] = cpu_baseline(num, cat, args.cpu_sample_rows, args.cpu_1t_sample_rows, n, m, args.nb)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COFACTOR_LIB", os.path.join(_HERE, "libcofactor_hip.so"))
 
 TRIPLE, NB = 0, 1
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = range(6)
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTERNAL = range(7)
 
 # every symbol include/cofactor_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -25,6 +25,8 @@ SYMBOLS = [
     "cofactor_agg_update_triples",
     "cofactor_agg_combine", "cofactor_agg_finalize",
     "cofactor_dense_len", "cofactor_agg_export_dense_device", "cofactor_agg_import_dense_device",
+    "cofactor_agg_keys", "cofactor_agg_dict_signature", "cofactor_agg_align_keys",
+    "cofactor_agg_tables_len", "cofactor_agg_export_tables_device", "cofactor_agg_import_tables_device",
     "cofactor_lift_host", "cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub",
     "cofactor_blob_len",
     "cofactor_linreg_train", "cofactor_lda_train",
@@ -79,14 +81,21 @@ def lib():
         L.cofactor_dense_len.restype = u64
         L.cofactor_agg_export_dense_device.argtypes = [vp, vp]
         L.cofactor_agg_import_dense_device.argtypes = [vp, vp]
+        L.cofactor_agg_keys.argtypes = [vp, vp, u64, pu64, vp]
+        L.cofactor_agg_dict_signature.argtypes = [vp, pu64]
+        L.cofactor_agg_align_keys.argtypes = [vp, vp, vp]
+        L.cofactor_agg_tables_len.argtypes = [vp]
+        L.cofactor_agg_tables_len.restype = u64
+        L.cofactor_agg_export_tables_device.argtypes = [vp, vp]
+        L.cofactor_agg_import_tables_device.argtypes = [vp, vp]
         L.cofactor_lift_host.argtypes = [pp, C.c_int, pp, C.c_int, u64, C.c_int, vp, u64, pu64, vp]
         for f in ("cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub"):
-            getattr(L, f).argtypes = [vp, vp, vp, u64, pu64]
-        L.cofactor_blob_len.argtypes = [vp]
+            getattr(L, f).argtypes = [vp, u64, vp, u64, vp, u64, pu64]
+        L.cofactor_blob_len.argtypes = [vp, u64]
         L.cofactor_blob_len.restype = u64
         i32, f32 = C.c_int32, C.c_float
-        L.cofactor_linreg_train.argtypes = [vp, i32, f32, f32, i32, i32, i32, vp, u64, pu64]
-        L.cofactor_lda_train.argtypes = [vp, i32, f32, i32, vp, u64, pu64]
+        L.cofactor_linreg_train.argtypes = [vp, u64, i32, f32, f32, i32, i32, i32, vp, u64, pu64]
+        L.cofactor_lda_train.argtypes = [vp, u64, i32, f32, i32, vp, u64, pu64]
         L.cofactor_linreg_predict_device.argtypes = [vp, vp, u64, i32, i32, u64, pp, i32, pp, i32, vp, u64, vp]
         L.cofactor_lda_predict_device.argtypes = [vp, vp, u64, i32, i32, pp, i32, pp, i32, vp, u64, vp]
         L.cofactor_linreg_predict_host.argtypes = [vp, vp, u64, i32, i32, u64, pp, i32, pp, i32, u64, vp]
@@ -337,6 +346,36 @@ class Aggregate:
     def import_dense_device(self, ptr):
         _check(lib().cofactor_agg_import_dense_device(self._h, ptr))
 
+    # ---- dictionary-aligned table seam (multi-GPU) ----
+    def keys(self):
+        """-> (keys int32[total], offsets uint64[m+1]): the state's keys per column, ascending."""
+        need = C.c_uint64(0)
+        offs = np.zeros(self.m + 1, dtype=np.uint64)
+        _check(lib().cofactor_agg_keys(self._h, None, 0, C.byref(need), None))
+        out = np.empty(max(1, need.value), dtype=np.int32)
+        _check(lib().cofactor_agg_keys(self._h, out.ctypes.data, out.size, C.byref(need), offs.ctypes.data))
+        return out[:need.value], offs
+
+    def dict_signature(self):
+        sig = C.c_uint64(0)
+        _check(lib().cofactor_agg_dict_signature(self._h, C.byref(sig)))
+        return sig.value
+
+    def align_keys(self, keys, offsets):
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        assert o.size == self.m + 1
+        _check(lib().cofactor_agg_align_keys(self._h, k.ctypes.data if k.size else None, o.ctypes.data))
+
+    def tables_len(self):
+        return lib().cofactor_agg_tables_len(self._h)
+
+    def export_tables_device(self, ptr):
+        _check(lib().cofactor_agg_export_tables_device(self._h, ptr))
+
+    def import_tables_device(self, ptr):
+        _check(lib().cofactor_agg_import_tables_device(self._h, ptr))
+
 
 def lift_host(num_cols, cat_cols, kind=TRIPLE):
     """to_cofactor / to_nb_agg: list of one blob per row."""
@@ -356,7 +395,7 @@ def lift_host(num_cols, cat_cols, kind=TRIPLE):
 def _binary(fn, a, b):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
-    return _two_call(fn, a.ctypes.data, b.ctypes.data)
+    return _two_call(fn, a.ctypes.data, a.size, b.ctypes.data, b.size)
 
 
 def multiply(a, b):
@@ -384,16 +423,16 @@ def linreg_train(triple, label, step_size=0.001, lam=0.0, max_iterations=10000,
     """linreg_train(triple, label, learning_rate, regularization, max_iterations,
     include_variance, normalize) -> float32 parameter vector (host; no GPU involved)."""
     b = np.ascontiguousarray(triple, dtype=np.float64)
-    return _two_call_f32(lib().cofactor_linreg_train, b.ctypes.data, label, step_size, lam,
+    return _two_call_f32(lib().cofactor_linreg_train, b.ctypes.data, b.size, label, step_size, lam,
                          max_iterations, int(compute_variance), int(normalize))
 
 
 def lda_train(triple, label, shrinkage=0.0, normalize=False):
     """lda_train(triple, label, shrinkage, normalize) -> float32 parameter vector (host)."""
     b = np.ascontiguousarray(triple, dtype=np.float64)
-    return _two_call_f32(lib().cofactor_lda_train, b.ctypes.data, label, shrinkage, int(normalize))
+    return _two_call_f32(lib().cofactor_lda_train, b.ctypes.data, b.size, label, shrinkage, int(normalize))
 
 
 def blob_len(blob):
     b = np.ascontiguousarray(blob, dtype=np.float64)
-    return lib().cofactor_blob_len(b.ctypes.data)
+    return lib().cofactor_blob_len(b.ctypes.data, b.size)

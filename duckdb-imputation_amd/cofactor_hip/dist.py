@@ -1,13 +1,23 @@
 """Multi-GPU seam of the aggregate: one process per GPU, rows sharded with no
-halo, ONE all-reduce of the dense partial triple (RCCL over xGMI when the backend is "nccl"), and
-the sparse categorical lists merged on the host from an all-gather of finalised blobs.
+halo, and the ranks' partial triples merged by ONE all-reduce (RCCL over xGMI when the backend is
+"nccl") of one device buffer
 
-Works with any initialised torch.distributed backend: "nccl" (= RCCL) on GPUs, "gloo" for the
-world-size-2 CPU tests (tests/test_dist_gloo.py), where the per-rank blobs come from elsewhere.
+    [ N, lin, quad | cnt | s | p ]
+
+— the dense part (Triple::SumStateCombine, sum_state.cpp:25,73-83) followed by the categorical
+tables re-indexed to a dictionary all ranks share (sum_state.cpp:87-111 as a dense sum).  Nothing
+travels through the host: export kernel -> all-reduce -> import kernel are chained on the
+library's own stream, which torch sees as an ExternalStream.
+
+Before the all-reduce the ranks make sure their dictionaries agree: a tiny all-gather of
+(signature, #keys per column); only if some rank met a new key since the last alignment are the key
+lists gathered and cofactor_agg_align_keys run.  In the steady state (a MICE loop over a fixed
+table) a step is one small all-gather and one all-reduce.
+
+Backends: "nccl" (= RCCL) on GPUs.  "gloo" stages the buffer through host memory — that is how the
+world-size-2 tests run two ranks on one GPU.
 """
 import numpy as np
-
-from . import add as _add_blobs
 
 
 def shard_bounds(rows, rank, world):
@@ -15,17 +25,121 @@ def shard_bounds(rows, rank, world):
     return rows * rank // world, rows * (rank + 1) // world
 
 
-def allreduce_dense(agg, dist, device):
-    """In place: the aggregate's N / lin / quad become the totals over all ranks.
-    GPU path: export to a device buffer -> dist.all_reduce(SUM) -> import."""
+def _seam_buffer(agg, length, device):
+    """Persistent device buffer of the aggregate (never handed back to torch's allocator while
+    kernels of the library's stream may still read it)."""
     import torch
-    buf = torch.zeros(int(agg.dense_len()), dtype=torch.float64, device=device)
-    agg.export_dense_device(buf.data_ptr())
-    dist.all_reduce(buf)
-    if buf.is_cuda:
-        torch.cuda.synchronize(device)
-    agg.import_dense_device(buf.data_ptr())
+    buf = getattr(agg, "_seam_buf", None)
+    if buf is None or buf.numel() < length or buf.device != torch.device(device):
+        buf = torch.empty(max(256, int(length)), dtype=torch.float64, device=device)
+        agg._seam_buf = buf
+    return buf[:length]
 
+
+def _ctx_stream(agg, device):
+    import torch
+    st = getattr(agg.ctx, "_torch_stream", None)
+    if st is None:
+        st = torch.cuda.ExternalStream(agg.ctx.stream, device=device)
+        agg.ctx._torch_stream = st
+    return st
+
+
+def _gather_int64(vec, dist, device):
+    """all_gather of equally sized int64 vectors -> list of numpy arrays, one per rank."""
+    import torch
+    mine = torch.as_tensor(np.ascontiguousarray(vec, dtype=np.int64), device=device)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [o.cpu().numpy() for o in out]
+
+
+def align_dictionaries(agg, dist, comm_device):
+    """SURVEY.md §8e steps 1-2.  Returns True if the key lists had to be exchanged."""
+    if agg.m == 0:
+        return False
+    sig = agg.dict_signature()
+    keys = offs = None
+    if sig == 0:
+        keys, offs = agg.keys()
+        sizes = np.diff(offs.astype(np.int64))
+    else:
+        sizes = np.zeros(agg.m, dtype=np.int64)
+    # signature as two 31-bit halves + a third word: int64 all_gather keeps all 64 bits, split only
+    # to stay clear of sign handling
+    head = np.array([sig & 0x7FFFFFFF, (sig >> 31) & 0x7FFFFFFF, sig >> 62], dtype=np.int64)
+    got = _gather_int64(np.concatenate([head, sizes]), dist, comm_device)
+    sigs = {tuple(g[:3]) for g in got}
+    if len(sigs) == 1 and sig != 0:
+        return False                                   # every rank still holds the common dictionary
+    if keys is None:
+        keys, offs = agg.keys()
+    # (ranks that were aligned reported zero sizes: gather the real ones)
+    sizes_all = _gather_int64(np.diff(offs.astype(np.int64)), dist, comm_device)
+    longest = int(max(int(s.sum()) for s in sizes_all))
+    padded = np.zeros(max(1, longest), dtype=np.int64)
+    padded[:keys.size] = keys
+    lists = _gather_int64(padded, dist, comm_device)
+    cols = [[] for _ in range(agg.m)]
+    for lst, sz in zip(lists, sizes_all):
+        pos = 0
+        for c in range(agg.m):
+            cols[c].append(lst[pos:pos + int(sz[c])])
+            pos += int(sz[c])
+    allk = [np.concatenate(c) if c else np.zeros(0, dtype=np.int64) for c in cols]
+    goffs = np.zeros(agg.m + 1, dtype=np.uint64)
+    goffs[1:] = np.cumsum([a.size for a in allk])
+    agg.align_keys(np.concatenate(allk).astype(np.int32) if allk else np.zeros(0, np.int32), goffs)
+    return True
+
+
+def allreduce_state(agg, dist, device):
+    """In place: the aggregate becomes the merge of all ranks' aggregates (dense totals and, after
+    dictionary alignment, every categorical table).  One all-reduce."""
+    import torch
+    backend = dist.get_backend()
+    on_gpu = torch.device(device).type == "cuda"
+    comm_device = device if (backend == "nccl" and on_gpu) else "cpu"
+    align_dictionaries(agg, dist, comm_device)
+    dlen, tlen = int(agg.dense_len()), int(agg.tables_len())
+    buf = _seam_buffer(agg, dlen + tlen, device)
+    dptr = buf.data_ptr()
+    if backend == "nccl":
+        with torch.cuda.stream(_ctx_stream(agg, device)):
+            agg.export_dense_device(dptr)
+            if tlen:
+                agg.export_tables_device(dptr + 8 * dlen)
+            dist.all_reduce(buf)                       # RCCL, ordered after / before our kernels by stream events
+            agg.import_dense_device(dptr)
+            if tlen:
+                agg.import_tables_device(dptr + 8 * dlen)
+    else:                                              # gloo: the same seam, staged through host memory
+        agg.export_dense_device(dptr)
+        if tlen:
+            agg.export_tables_device(dptr + 8 * dlen)
+        agg.ctx.synchronize()
+        host = buf.cpu()
+        dist.all_reduce(host)
+        buf.copy_(host)
+        torch.cuda.current_stream(buf.device).synchronize()
+        agg.import_dense_device(dptr)
+        if tlen:
+            agg.import_tables_device(dptr + 8 * dlen)
+
+
+def allreduce_dense(agg, dist, device):
+    """Dense part only (m = 0 aggregates, or callers that merge the lists themselves)."""
+    assert agg.m == 0, "allreduce_dense is for aggregates without key columns; use allreduce_state"
+    allreduce_state(agg, dist, device)
+
+
+def allreduce_triple(agg, dist, device):
+    """The reduced triple (flat blob), identical on every rank."""
+    allreduce_state(agg, dist, device)
+    return agg.finalize()
+
+
+# ---- blob-level helpers (CPU tests of the host merge; not on the GPU path any more) ----------------
 
 def allgather_blobs(blob, dist, device="cpu"):
     """Every rank's finalised blob on every rank (variable length: sizes first, then padded)."""
@@ -45,27 +159,8 @@ def allgather_blobs(blob, dist, device="cpu"):
 def merge_blobs(blobs):
     """Fold finalised triples in rank order with the library's Value-level add
     (cofactor_triple_add = Triple::sum_triple, imputation/triple/sum.cpp:68-209)."""
+    from . import add as _add_blobs
     total = np.ascontiguousarray(blobs[0], dtype=np.float64)
     for b in blobs[1:]:
         total = _add_blobs(total, b)
     return total
-
-
-def allreduce_triple(agg, dist, device):
-    """The reduced triple (flat blob) on every rank.  Dense part: one all-reduce on the device.
-    Categorical part (m > 0): all-gather of the ranks' blobs, host merge in rank order; the
-    dense fields of the merged blob are then replaced by the all-reduced ones so that every rank
-    holds bit-identical values."""
-    allreduce_dense(agg, dist, device)
-    mine = agg.finalize()               # dense = global totals, lists = this rank's rows
-    if agg.m == 0:
-        return mine
-    blobs = allgather_blobs(mine, dist, device=device)
-    # each gathered blob carries the GLOBAL dense part; neutralise all but one before adding
-    n = agg.n
-    dense_len = int(agg.dense_len())
-    for b in blobs[1:]:
-        b[3:3 + dense_len] = 0.0
-    merged = merge_blobs(blobs)
-    merged[3:3 + dense_len] = mine[3:3 + dense_len]
-    return merged

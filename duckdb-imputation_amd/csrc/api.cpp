@@ -102,6 +102,12 @@ struct cofactor_agg {
   int32_t *h_cat = nullptr;
   float *d_num = nullptr;
   int32_t *d_cat = nullptr;
+  // dense seam: the host-side dense addends on their way to the export kernel
+  double *d_host_dense = nullptr;
+  std::vector<double> host_dense_stage;
+  // table seam: signature of the key lists the dictionaries were last aligned to (0 = the
+  // dictionaries have changed since, or were never aligned)
+  uint64_t dict_sig = 0;
 };
 
 namespace {
@@ -213,6 +219,8 @@ cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t r
     HIP_TRY(hipMemcpyAsync(counters + COFACTOR_MAX_CAT, a->D.flags, sizeof(int32_t) * 4,
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (counters[COFACTOR_MAX_CAT + 1])             // sticky: set by an accumulate kernel of an earlier update
+      return fail(COFACTOR_ERR_INTERNAL, "a row of an earlier update met a key missing from its dictionary");
     if (counters[COFACTOR_MAX_CAT] == 0) break;
     if (attempt > 24) return fail(COFACTOR_ERR_UNSUPPORTED, "dictionary growth did not converge");
     CatLayout Ln = a->L;                          // a dictionary ran full: quadruple all of them
@@ -231,6 +239,7 @@ cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t r
   bool grow = false;
   CatLayout Ln = a->L;
   for (int c = 0; c < a->m; c++) {
+    if (a->nkeys_host[c] != counters[c]) a->dict_sig = 0;   // a new key: no longer the aligned dictionary
     a->nkeys_host[c] = counters[c];
     if (counters[c] > Ln.kc[c]) { Ln.kc[c] = next_pow2(counters[c]); grow = true; }
     while (counters[c] * 2 > Ln.ht_cap[c]) { Ln.ht_cap[c] *= 2; grow = true; }  // load factor <= 1/2
@@ -460,6 +469,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
 cofactor_status stage_alloc(cofactor_agg *a, uint64_t cap) {
   CTX_LOCK(a->ctx);
   if (a->stage_cap) {
+    a->stage_cap = 0;                              // a failure below must not leave a capacity without buffers
     HIP_TRY(hipStreamSynchronize(a->ctx->stream));
     if (a->h_num) (void)hipHostFree(a->h_num);
     if (a->h_cat) (void)hipHostFree(a->h_cat);
@@ -527,16 +537,16 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
   hipStream_t st = a->ctx->stream;
   out.shape(a->kind, a->n, a->m);
   out.N = a->dev_rows;
+  std::vector<double> acc(GRAM_ACC_LEN, 0.0);
   if (a->dev_dirty) {
     unsigned long long kept = 0;
     HIP_TRY(hipMemcpyAsync(&kept, a->d_kept, sizeof(kept), hipMemcpyDeviceToHost, st));
+    if (a->n > 0)
+      HIP_TRY(hipMemcpyAsync(acc.data(), a->d_acc, sizeof(double) * GRAM_ACC_LEN, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     out.N += (double)kept;
   }
-  std::vector<double> acc(GRAM_ACC_LEN, 0.0);
   if (a->n > 0 && a->dev_dirty) {
-    HIP_TRY(hipMemcpyAsync(acc.data(), a->d_acc, sizeof(double) * GRAM_ACC_LEN, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
     for (int c = 0; c < a->n; c++) out.lin[c] = acc[gram_lin_pos(c, a->n)];
     if (a->kind == COFACTOR_NB) {
       for (int j = 0; j < a->n; j++) out.quad[j] = acc[gram_quad_pos(j, j, a->n)];
@@ -559,7 +569,7 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
     int32_t flags[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(flags, a->D.flags, sizeof(flags), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (flags[1]) return fail(COFACTOR_ERR_HIP, "internal error: a row met a key missing from its dictionary");
+    if (flags[1]) return fail(COFACTOR_ERR_INTERNAL, "a row met a key missing from its dictionary");
     a->cat_check_pending = false;
     std::vector<std::vector<int32_t>> key_of(a->m);
     std::vector<std::vector<char>> live(a->m);
@@ -747,6 +757,7 @@ void cofactor_agg_destroy(cofactor_agg *a) {
     if (e) (void)hipEventDestroy(e);
   (void)hipFree(a->d_num);
   (void)hipFree(a->d_cat);
+  (void)hipFree(a->d_host_dense);
   delete a;
 }
 
@@ -881,7 +892,8 @@ cofactor_status cofactor_agg_update_triples(cofactor_agg *a, const double *blobs
   ListTriple t;
   std::string err;
   for (uint64_t i = 0; i < count; i++) {
-    if (!blob_decode(blobs + offsets[i], t, err)) return fail(COFACTOR_ERR_INVALID, err);
+    if (offsets[i + 1] < offsets[i]) return fail(COFACTOR_ERR_INVALID, "update_triples: offsets must ascend");
+    if (!blob_decode(blobs + offsets[i], offsets[i + 1] - offsets[i], t, err)) return fail(COFACTOR_ERR_INVALID, err);
     if (!a->host.add_list(t, err)) return fail(COFACTOR_ERR_INVALID, err);
   }
   return COFACTOR_OK;
@@ -941,46 +953,281 @@ uint64_t cofactor_dense_len(int n_num, cofactor_kind kind) {
 cofactor_status cofactor_agg_export_dense_device(cofactor_agg *a, double *d_out) {
   if (!a || !d_out) return fail(COFACTOR_ERR_INVALID, "null argument");
   CTX_LOCK(a->ctx);
-  HostTriple snap;
-  cofactor_status s = snapshot(a, snap, /*dense_only=*/true);
-  if (s != COFACTOR_OK) return s;
-  std::vector<double> v;
-  v.push_back(snap.N);
-  v.insert(v.end(), snap.lin.begin(), snap.lin.end());
-  v.insert(v.end(), snap.quad.begin(), snap.quad.end());
   DeviceGuard guard(a->ctx->device);
-  HIP_TRY(hipMemcpyAsync(d_out, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, a->ctx->stream));
-  HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  cofactor_status s = stage_flush(a);             // rows still staged on the host belong to the totals
+  if (s != COFACTOR_OK) return s;
+  hipStream_t st = a->ctx->stream;
+  // whatever the state holds on the host (combine, lifted triples) rides along as an addend
+  const uint64_t len = cofactor_dense_len(a->n, (cofactor_kind)a->kind);
+  bool host_dense = a->host.N != 0;
+  for (double v : a->host.lin) host_dense = host_dense || v != 0;
+  for (double v : a->host.quad) host_dense = host_dense || v != 0;
+  const double *extra = nullptr;
+  if (host_dense) {
+    if (!a->d_host_dense) HIP_TRY(hipMalloc((void **)&a->d_host_dense, sizeof(double) * 256));
+    a->host_dense_stage.assign(1, a->host.N);
+    a->host_dense_stage.insert(a->host_dense_stage.end(), a->host.lin.begin(), a->host.lin.end());
+    a->host_dense_stage.insert(a->host_dense_stage.end(), a->host.quad.begin(), a->host.quad.end());
+    HIP_TRY(hipMemcpyAsync(a->d_host_dense, a->host_dense_stage.data(), len * sizeof(double),
+                           hipMemcpyHostToDevice, st));
+    extra = a->d_host_dense;
+  }
+  HIP_TRY(launch_dense_export(a->d_acc, a->d_kept, a->dev_rows, extra, a->n, a->kind, d_out, st));
   return COFACTOR_OK;
 }
 
 cofactor_status cofactor_agg_import_dense_device(cofactor_agg *a, const double *d_in) {
   if (!a || !d_in) return fail(COFACTOR_ERR_INVALID, "null argument");
   CTX_LOCK(a->ctx);
-  // 1. pull everything the device holds into the host accumulator ...
-  HostTriple snap;
-  cofactor_status s = snapshot(a, snap);
-  if (s != COFACTOR_OK) return s;
   DeviceGuard guard(a->ctx->device);
-  hipStream_t st = a->ctx->stream;
-  std::vector<double> v(cofactor_dense_len(a->n, (cofactor_kind)a->kind));
-  HIP_TRY(hipMemcpyAsync(v.data(), d_in, v.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemsetAsync(a->d_acc, 0, sizeof(double) * GRAM_ACC_LEN, st));
-  if (a->cat_ready) {
-    HIP_TRY(hipMemsetAsync(a->D.cnt, 0, sizeof(unsigned long long) * std::max(1, a->L.n_cnt), st));
-    HIP_TRY(hipMemsetAsync(a->D.s, 0, sizeof(double) * std::max(1, a->L.n_s), st));
-    HIP_TRY(hipMemsetAsync(a->D.p, 0, sizeof(unsigned long long) * std::max(1, a->L.n_p), st));
-  }
-  HIP_TRY(hipMemsetAsync(a->d_kept, 0, sizeof(unsigned long long), st));
-  HIP_TRY(hipStreamSynchronize(st));
+  cofactor_status s = stage_flush(a);
+  if (s != COFACTOR_OK) return s;
+  // the accumulator image and the kept-row counter become the imported totals; the host-side
+  // dense addends are part of those totals now.  Categorical tables are not touched.
+  HIP_TRY(launch_dense_import(d_in, a->n, a->kind, a->d_acc, a->d_kept, a->ctx->stream));
   a->dev_rows = 0;
-  a->dev_dirty = false;
+  a->dev_dirty = true;
   a->blob_cache_valid = false;
-  a->host = std::move(snap);
-  // 2. ... then replace its dense totals by the reduced ones
-  a->host.N = v[0];
-  for (int k = 0; k < a->n; k++) a->host.lin[k] = v[1 + k];
-  for (size_t k = 0; k < a->host.quad.size(); k++) a->host.quad[k] = v[1 + a->n + k];
+  a->host.N = 0;
+  std::fill(a->host.lin.begin(), a->host.lin.end(), 0.0);
+  std::fill(a->host.quad.begin(), a->host.quad.end(), 0.0);
+  return COFACTOR_OK;
+}
+
+// ---- dictionary-aligned table seam ----------------------------------------
+
+namespace {
+
+// every key a state knows, per column, ascending: device dictionary + host-side maps
+cofactor_status collect_keys(cofactor_agg *a, std::vector<std::vector<int32_t>> &keys,
+                             std::vector<unsigned long long> *slots_out = nullptr,
+                             std::vector<int32_t> *codes_out = nullptr) {
+  keys.assign(a->m, {});
+  if (a->m > 0 && a->cat_ready) {
+    hipStream_t st = a->ctx->stream;
+    const CatLayout &L = a->L;
+    std::vector<unsigned long long> slot(L.n_slots);
+    std::vector<int32_t> code(L.n_slots);
+    HIP_TRY(hipMemcpyAsync(slot.data(), a->D.ht_slot, sizeof(unsigned long long) * L.n_slots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(code.data(), a->D.ht_code, sizeof(int32_t) * L.n_slots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int c = 0; c < a->m; c++)
+      for (int i = 0; i < L.ht_cap[c]; i++) {
+        const unsigned long long v = slot[L.ht_off[c] + i];
+        if (v != 0ull && code[L.ht_off[c] + i] >= 0) keys[c].push_back((int32_t)(unsigned)(v & 0xffffffffull));
+      }
+    if (slots_out) *slots_out = std::move(slot);
+    if (codes_out) *codes_out = std::move(code);
+  }
+  for (int c = 0; c < a->m; c++) {
+    for (auto const &kv : a->host.col[c]) keys[c].push_back(kv.first);
+    std::sort(keys[c].begin(), keys[c].end());
+    keys[c].erase(std::unique(keys[c].begin(), keys[c].end()), keys[c].end());
+  }
+  return COFACTOR_OK;
+}
+
+uint64_t keys_signature(const std::vector<std::vector<int32_t>> &keys) {
+  uint64_t h = 0xcbf29ce484222325ull;               // FNV-1a over (column separator, keys)
+  auto mix = [&](uint64_t v) { for (int b = 0; b < 8; b++) { h ^= (v >> (8 * b)) & 0xff; h *= 0x100000001b3ull; } };
+  for (auto const &col : keys) {
+    mix(0xffffffffffffffffull ^ col.size());
+    for (int32_t k : col) mix((uint64_t)(uint32_t)k);
+  }
+  return h ? h : 1;
+}
+
+}  // namespace
+
+cofactor_status cofactor_agg_keys(cofactor_agg *a, int32_t *out, uint64_t cap, uint64_t *needed,
+                                  uint64_t *offsets) {
+  if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
+  CTX_LOCK(a->ctx);
+  DeviceGuard guard(a->ctx->device);
+  cofactor_status s = stage_flush(a);
+  if (s != COFACTOR_OK) return s;
+  std::vector<std::vector<int32_t>> keys;
+  s = collect_keys(a, keys);
+  if (s != COFACTOR_OK) return s;
+  uint64_t total = 0;
+  for (auto const &k : keys) total += k.size();
+  if (needed) *needed = total;
+  if (!out) return COFACTOR_OK;
+  if (cap < total) return fail(COFACTOR_ERR_CAPACITY, "output buffer too small");
+  uint64_t pos = 0;
+  for (int c = 0; c < a->m; c++) {
+    if (offsets) offsets[c] = pos;
+    std::copy(keys[c].begin(), keys[c].end(), out + pos);
+    pos += keys[c].size();
+  }
+  if (offsets) offsets[a->m] = pos;
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_dict_signature(cofactor_agg *a, uint64_t *sig) {
+  if (!a || !sig) return fail(COFACTOR_ERR_INVALID, "null argument");
+  CTX_LOCK(a->ctx);
+  bool host_keys = false;
+  for (auto const &c : a->host.col) host_keys = host_keys || !c.empty();
+  for (auto const &t : a->host.pair) host_keys = host_keys || !t.empty();
+  *sig = (a->stage_rows > 0 || host_keys) ? 0 : a->dict_sig;
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_align_keys(cofactor_agg *a, const int32_t *keys_in, const uint64_t *offsets) {
+  if (!a || (a->m > 0 && !offsets)) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (a->m == 0) return COFACTOR_OK;
+  CTX_LOCK(a->ctx);
+  DeviceGuard guard(a->ctx->device);
+  cofactor_status s = stage_flush(a);
+  if (s != COFACTOR_OK) return s;
+  s = cat_prepare(a);
+  if (s != COFACTOR_OK) return s;
+  hipStream_t st = a->ctx->stream;
+  // the global key lists: whatever was handed in (any order, duplicates allowed: the
+  // concatenation of all ranks' lists), sorted and made unique here
+  std::vector<std::vector<int32_t>> G(a->m);
+  for (int c = 0; c < a->m; c++) {
+    if (offsets[c + 1] < offsets[c]) return fail(COFACTOR_ERR_INVALID, "align_keys: offsets must ascend");
+    if (offsets[c + 1] > offsets[c] && !keys_in) return fail(COFACTOR_ERR_INVALID, "null argument");
+    G[c].assign(keys_in + offsets[c], keys_in + offsets[c + 1]);
+    std::sort(G[c].begin(), G[c].end());
+    G[c].erase(std::unique(G[c].begin(), G[c].end()), G[c].end());
+    if (G[c].size() > (1u << 27)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical column has too many distinct keys");
+  }
+  std::vector<std::vector<int32_t>> own;
+  std::vector<unsigned long long> old_slot;
+  std::vector<int32_t> old_code;
+  s = collect_keys(a, own, &old_slot, &old_code);
+  if (s != COFACTOR_OK) return s;
+  for (int c = 0; c < a->m; c++)
+    if (!std::includes(G[c].begin(), G[c].end(), own[c].begin(), own[c].end()))
+      return fail(COFACTOR_ERR_INVALID, "align_keys: the key lists lack a key this state holds");
+  const CatLayout Lo = a->L;
+  CatLayout Ln{};
+  Ln.n = a->n; Ln.m = a->m; Ln.kind = a->kind;
+  for (int c = 0; c < a->m; c++) {
+    Ln.kc[c] = std::max(16, next_pow2((int)G[c].size()));
+    Ln.ht_cap[c] = std::max(64, next_pow2(2 * (int)G[c].size()));
+  }
+  if (!cat_finish_layout(Ln))
+    return fail(COFACTOR_ERR_UNSUPPORTED, "categorical cardinalities too high for dense code-indexed pair tables");
+  // aligned dictionary (code = rank of the key in the global list) and old code -> new code
+  std::vector<unsigned long long> nslot(Ln.n_slots, 0ull);
+  std::vector<int32_t> ncode(Ln.n_slots, -1), remap(std::max(1, Lo.n_cnt), -1);
+  for (int c = 0; c < a->m; c++) {
+    const int cap = Ln.ht_cap[c];
+    for (size_t g = 0; g < G[c].size(); g++) {
+      unsigned h = cat_hash_key(G[c][g], cap);
+      while (nslot[Ln.ht_off[c] + h] != 0ull) h = (h + 1) & (cap - 1);
+      nslot[Ln.ht_off[c] + h] = (1ull << 32) | (unsigned long long)(unsigned)G[c][g];
+      ncode[Ln.ht_off[c] + h] = (int32_t)g;
+    }
+    for (int i = 0; i < Lo.ht_cap[c]; i++) {
+      const unsigned long long v = old_slot[Lo.ht_off[c] + i];
+      const int32_t cd = old_code[Lo.ht_off[c] + i];
+      if (v == 0ull || cd < 0 || cd >= Lo.kc[c]) continue;
+      const int32_t key = (int32_t)(unsigned)(v & 0xffffffffull);
+      remap[Lo.cnt_off[c] + cd] = (int32_t)(std::lower_bound(G[c].begin(), G[c].end(), key) - G[c].begin());
+    }
+  }
+  CatDevice Dn;
+  s = cat_alloc(Ln, Dn, false, st);
+  if (s != COFACTOR_OK) return s;
+  Dn.nkeys = a->D.nkeys;
+  Dn.flags = a->D.flags;
+  int32_t *d_remap = nullptr;
+  int32_t nk[COFACTOR_MAX_CAT] = {0};
+  for (int c = 0; c < a->m; c++) nk[c] = (int32_t)G[c].size();
+  hipError_t e = hipMalloc((void **)&d_remap, sizeof(int32_t) * remap.size());
+  if (e == hipSuccess) e = hipMemcpyAsync(d_remap, remap.data(), sizeof(int32_t) * remap.size(), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(Dn.ht_slot, nslot.data(), sizeof(unsigned long long) * Ln.n_slots, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(Dn.ht_code, ncode.data(), sizeof(int32_t) * Ln.n_slots, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(Dn.nkeys, nk, sizeof(nk), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = launch_cat_remap(Lo, a->D, Ln, Dn, d_remap, st);
+  // what the state holds on the host under keys goes into the (now dense and aligned) tables
+  bool host_keys = false;
+  for (auto const &c : a->host.col) host_keys = host_keys || !c.empty();
+  for (auto const &t : a->host.pair) host_keys = host_keys || !t.empty();
+  double *d_add = nullptr;
+  std::vector<double> addv;
+  if (e == hipSuccess && host_keys) {
+    addv.assign((size_t)Ln.n_cnt + Ln.n_s + Ln.n_p, 0.0);
+    auto code_of = [&](int c, int32_t key) { return (size_t)(std::lower_bound(G[c].begin(), G[c].end(), key) - G[c].begin()); };
+    for (int c = 0; c < a->m; c++)
+      for (auto const &kv : a->host.col[c]) {
+        const size_t cd = code_of(c, kv.first);
+        addv[Ln.cnt_off[c] + cd] += kv.second[0];
+        if (!a->kind)
+          for (int k = 0; k < a->n; k++) addv[(size_t)Ln.n_cnt + Ln.s_off[c] + cd * a->n + k] += kv.second[k + 1];
+      }
+    if (!a->kind) {
+      int q = 0;
+      for (int c1 = 0; c1 < a->m; c1++)
+        for (int c2 = c1; c2 < a->m; c2++, q++)
+          for (auto const &kv : a->host.pair[q]) {
+            // a pair's keys are keys of their columns' lin_cat lists (same rows), hence in G
+            const size_t k1 = code_of(c1, kv.first.first), k2 = code_of(c2, kv.first.second);
+            if (k1 >= G[c1].size() || k2 >= G[c2].size() || G[c1][k1] != kv.first.first || G[c2][k2] != kv.first.second) {
+              e = hipErrorInvalidValue;
+              continue;
+            }
+            addv[(size_t)Ln.n_cnt + Ln.n_s + Ln.p_off[q] + k1 * Ln.kc[c2] + k2] += kv.second;
+          }
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&d_add, sizeof(double) * addv.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(d_add, addv.data(), sizeof(double) * addv.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_cat_tables_import(Ln, Dn, d_add, /*add=*/true, st);
+  }
+  hipError_t es = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = es;
+  (void)hipFree(d_remap);
+  (void)hipFree(d_add);
+  if (e != hipSuccess) {
+    Dn.nkeys = nullptr; Dn.flags = nullptr;
+    cat_free(Dn);
+    return e == hipErrorInvalidValue ? fail(COFACTOR_ERR_INVALID, "align_keys: a host-side pair key is missing from its column's keys")
+                                     : hip_fail(e, "align_keys");
+  }
+  CatDevice old = a->D;
+  old.nkeys = nullptr; old.flags = nullptr;
+  cat_free(old);
+  a->D = Dn;
+  a->L = Ln;
+  for (int c = 0; c < a->m; c++) a->nkeys_host[c] = nk[c];
+  if (host_keys) {
+    for (auto &c : a->host.col) c.clear();
+    for (auto &t : a->host.pair) t.clear();
+  }
+  a->dev_dirty = true;
+  a->blob_cache_valid = false;
+  a->dict_sig = keys_signature(G);
+  return COFACTOR_OK;
+}
+
+uint64_t cofactor_agg_tables_len(cofactor_agg *a) {
+  if (!a || a->m == 0 || !a->cat_ready) return 0;
+  return (uint64_t)a->L.n_cnt + (uint64_t)a->L.n_s + (uint64_t)a->L.n_p;
+}
+
+cofactor_status cofactor_agg_export_tables_device(cofactor_agg *a, double *d_out) {
+  if (!a || !d_out) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (a->m == 0 || !a->cat_ready) return COFACTOR_OK;
+  CTX_LOCK(a->ctx);
+  DeviceGuard guard(a->ctx->device);
+  if (a->stage_rows > 0) return fail(COFACTOR_ERR_INVALID, "export_tables: rows are still staged on the host (align first)");
+  HIP_TRY(launch_cat_tables_export(a->L, a->D, d_out, a->ctx->stream));
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_import_tables_device(cofactor_agg *a, const double *d_in) {
+  if (!a || !d_in) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (a->m == 0 || !a->cat_ready) return COFACTOR_OK;
+  CTX_LOCK(a->ctx);
+  DeviceGuard guard(a->ctx->device);
+  HIP_TRY(launch_cat_tables_import(a->L, a->D, d_in, /*add=*/false, a->ctx->stream));
+  a->dev_dirty = true;
+  a->blob_cache_valid = false;
   return COFACTOR_OK;
 }
 
@@ -1000,24 +1247,24 @@ cofactor_status cofactor_lift_host(const float *const *num, int n_num, const int
   return emit_blob(blob, out, cap, needed);
 }
 
-cofactor_status cofactor_triple_multiply(const double *a, const double *b, double *out, uint64_t cap,
-                                         uint64_t *needed) {
+cofactor_status cofactor_triple_multiply(const double *a, uint64_t a_len, const double *b, uint64_t b_len,
+                                         double *out, uint64_t cap, uint64_t *needed) {
   if (!a || !b) return fail(COFACTOR_ERR_INVALID, "null argument");
   ListTriple A, B, R;
   std::string err;
-  if (!blob_decode(a, A, err) || !blob_decode(b, B, err)) return fail(COFACTOR_ERR_INVALID, err);
+  if (!blob_decode(a, a_len, A, err) || !blob_decode(b, b_len, B, err)) return fail(COFACTOR_ERR_INVALID, err);
   if (!multiply(A, B, R, err)) return fail(COFACTOR_ERR_INVALID, err);
   std::vector<double> blob;
   blob_encode(R, blob);
   return emit_blob(blob, out, cap, needed);
 }
 
-static cofactor_status add_sub_impl(const double *a, const double *b, bool sub, double *out,
-                                    uint64_t cap, uint64_t *needed) {
+static cofactor_status add_sub_impl(const double *a, uint64_t a_len, const double *b, uint64_t b_len, bool sub,
+                                    double *out, uint64_t cap, uint64_t *needed) {
   if (!a || !b) return fail(COFACTOR_ERR_INVALID, "null argument");
   ListTriple A, B, R;
   std::string err, warn;
-  if (!blob_decode(a, A, err) || !blob_decode(b, B, err)) return fail(COFACTOR_ERR_INVALID, err);
+  if (!blob_decode(a, a_len, A, err) || !blob_decode(b, b_len, B, err)) return fail(COFACTOR_ERR_INVALID, err);
   if (A.kind != B.kind) return fail(COFACTOR_ERR_INVALID, "triple kinds differ");
   add_sub(A, B, sub, R, warn);
   g_err = warn;                                   // "" unless a subtract met an unknown key
@@ -1026,16 +1273,16 @@ static cofactor_status add_sub_impl(const double *a, const double *b, bool sub, 
   return emit_blob(blob, out, cap, needed);
 }
 
-cofactor_status cofactor_triple_add(const double *a, const double *b, double *out, uint64_t cap,
-                                    uint64_t *needed) {
-  return add_sub_impl(a, b, false, out, cap, needed);
+cofactor_status cofactor_triple_add(const double *a, uint64_t a_len, const double *b, uint64_t b_len,
+                                    double *out, uint64_t cap, uint64_t *needed) {
+  return add_sub_impl(a, a_len, b, b_len, false, out, cap, needed);
 }
-cofactor_status cofactor_triple_sub(const double *a, const double *b, double *out, uint64_t cap,
-                                    uint64_t *needed) {
-  return add_sub_impl(a, b, true, out, cap, needed);
+cofactor_status cofactor_triple_sub(const double *a, uint64_t a_len, const double *b, uint64_t b_len,
+                                    double *out, uint64_t cap, uint64_t *needed) {
+  return add_sub_impl(a, a_len, b, b_len, true, out, cap, needed);
 }
 
-uint64_t cofactor_blob_len(const double *blob) { return blob_len(blob); }
+uint64_t cofactor_blob_len(const double *blob, uint64_t cap) { return blob_len(blob, cap); }
 
 // ---- consumers of the triple ----------------------------------------------------------------------
 
@@ -1048,14 +1295,14 @@ static cofactor_status emit_floats(const std::vector<float> &v, float *out, uint
   return COFACTOR_OK;
 }
 
-cofactor_status cofactor_linreg_train(const double *triple, int32_t label, float step_size,
+cofactor_status cofactor_linreg_train(const double *triple, uint64_t triple_len, int32_t label, float step_size,
                                       float lambda, int32_t max_iterations,
                                       int32_t compute_variance, int32_t normalize, float *out,
                                       uint64_t cap, uint64_t *needed) {
   if (!triple) return fail(COFACTOR_ERR_INVALID, "null argument");
   ListTriple t;
   std::string err;
-  if (!blob_decode(triple, t, err)) return fail(COFACTOR_ERR_INVALID, err);
+  if (!blob_decode(triple, triple_len, t, err)) return fail(COFACTOR_ERR_INVALID, err);
   std::vector<float> params;
   if (!linreg_train(t, label, step_size, lambda, max_iterations, compute_variance != 0,
                     normalize != 0, params, err))
@@ -1063,12 +1310,12 @@ cofactor_status cofactor_linreg_train(const double *triple, int32_t label, float
   return emit_floats(params, out, cap, needed);
 }
 
-cofactor_status cofactor_lda_train(const double *triple, int32_t label, float shrinkage,
+cofactor_status cofactor_lda_train(const double *triple, uint64_t triple_len, int32_t label, float shrinkage,
                                    int32_t normalize, float *out, uint64_t cap, uint64_t *needed) {
   if (!triple) return fail(COFACTOR_ERR_INVALID, "null argument");
   ListTriple t;
   std::string err;
-  if (!blob_decode(triple, t, err)) return fail(COFACTOR_ERR_INVALID, err);
+  if (!blob_decode(triple, triple_len, t, err)) return fail(COFACTOR_ERR_INVALID, err);
   std::vector<float> params;
   if (!lda_train(t, label, shrinkage, normalize != 0, params, err))
     return fail(COFACTOR_ERR_INVALID, err);

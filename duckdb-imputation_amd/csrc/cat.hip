@@ -16,6 +16,8 @@
 // otherwise it adds straight into the global tables.
 #include "device.hpp"
 
+#include <algorithm>
+
 namespace cofactor {
 
 namespace {
@@ -417,6 +419,94 @@ hipError_t launch_cat_accumulate(const NumCols &num, const CatCols &cat, uint64_
   if (le != hipSuccess) return le;
   if (ev1) return hipEventRecord(ev1, stream);
   return hipSuccess;
+}
+
+// ---- dictionary-aligned table seam of the multi-GPU path -----------------
+// Moves every accumulated value from the old code of its key to the new one (remap[cnt_off_old[c] +
+// old code] = new code, -1 for unused codes).  remap is injective per column: plain stores into
+// the freshly zeroed new tables.
+__global__ __launch_bounds__(256) void cat_remap_kernel(CatLayout Lo, CatDevice Do, CatLayout Ln,
+                                                        CatDevice Dn, const int32_t *__restrict__ remap) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+  for (long long i = tid; i < Lo.n_cnt; i += nth) {
+    int c = 0;
+    while (c + 1 < Lo.m && i >= Lo.cnt_off[c + 1]) c++;
+    const int nc = remap[i];
+    if (nc >= 0) Dn.cnt[Ln.cnt_off[c] + nc] = Do.cnt[i];
+  }
+  if (Lo.kind != 0) return;
+  for (long long i = tid; i < Lo.n_s; i += nth) {
+    int c = 0;
+    while (c + 1 < Lo.m && i >= Lo.s_off[c + 1]) c++;
+    const int local = (int)(i - Lo.s_off[c]);
+    const int code = local / Lo.n, k = local % Lo.n;
+    const int nc = remap[Lo.cnt_off[c] + code];
+    if (nc >= 0) Dn.s[Ln.s_off[c] + (long long)nc * Ln.n + k] = Do.s[i];
+  }
+  const int npairs = Lo.m * (Lo.m + 1) / 2;
+  for (long long i = tid; i < Lo.n_p; i += nth) {
+    const unsigned long long v = Do.p[i];
+    if (!v) continue;
+    int q = 0;
+    while (q + 1 < npairs && i >= Lo.p_off[q + 1]) q++;
+    int c1 = 0, rem = q;
+    while (rem >= Lo.m - c1) { rem -= Lo.m - c1; c1++; }
+    const int c2 = c1 + rem;
+    const int local = (int)(i - Lo.p_off[q]);
+    const int n1 = remap[Lo.cnt_off[c1] + local / Lo.kc[c2]], n2 = remap[Lo.cnt_off[c2] + local % Lo.kc[c2]];
+    if (n1 >= 0 && n2 >= 0) Dn.p[Ln.p_off[q] + (long long)n1 * Ln.kc[c2] + n2] = v;
+  }
+}
+
+// [cnt | s | p] as ONE array of doubles (counts are exact integers below 2^53) and back.
+// add != 0: the values are added to the tables instead of replacing them.
+__global__ __launch_bounds__(256) void cat_tables_export_kernel(CatLayout L, CatDevice D, double *__restrict__ out) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+  const long long total = (long long)L.n_cnt + L.n_s + L.n_p;
+  for (long long i = tid; i < total; i += nth) {
+    double v;
+    if (i < L.n_cnt) v = (double)D.cnt[i];
+    else if (i < (long long)L.n_cnt + L.n_s) v = D.s[i - L.n_cnt];
+    else v = (double)D.p[i - L.n_cnt - L.n_s];
+    out[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void cat_tables_import_kernel(CatLayout L, CatDevice D, const double *__restrict__ in,
+                                                                int add) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+  const long long total = (long long)L.n_cnt + L.n_s + L.n_p;
+  for (long long i = tid; i < total; i += nth) {
+    const double v = in[i];
+    if (i < L.n_cnt) D.cnt[i] = (add ? D.cnt[i] : 0ull) + (unsigned long long)(v + 0.5);
+    else if (i < (long long)L.n_cnt + L.n_s) D.s[i - L.n_cnt] = (add ? D.s[i - L.n_cnt] : 0.0) + v;
+    else D.p[i - L.n_cnt - L.n_s] = (add ? D.p[i - L.n_cnt - L.n_s] : 0ull) + (unsigned long long)(v + 0.5);
+  }
+}
+
+hipError_t launch_cat_remap(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
+                            const CatDevice &Dnew, const int32_t *remap, hipStream_t stream) {
+  if (Lold.m == 0) return hipSuccess;
+  const long long cells = std::max<long long>(Lold.n_p, std::max(Lold.n_s, Lold.n_cnt));
+  const int grid = (int)std::min<long long>(4096, (cells + 255) / 256);
+  hipLaunchKernelGGL(cat_remap_kernel, dim3(grid), dim3(256), 0, stream, Lold, Dold, Lnew, Dnew, remap);
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_tables_export(const CatLayout &L, const CatDevice &D, double *out, hipStream_t stream) {
+  const long long total = (long long)L.n_cnt + L.n_s + L.n_p;
+  if (total == 0) return hipSuccess;
+  const int grid = (int)std::min<long long>(4096, (total + 255) / 256);
+  hipLaunchKernelGGL(cat_tables_export_kernel, dim3(grid), dim3(256), 0, stream, L, D, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_tables_import(const CatLayout &L, const CatDevice &D, const double *in, bool add,
+                                    hipStream_t stream) {
+  const long long total = (long long)L.n_cnt + L.n_s + L.n_p;
+  if (total == 0) return hipSuccess;
+  const int grid = (int)std::min<long long>(4096, (total + 255) / 256);
+  hipLaunchKernelGGL(cat_tables_import_kernel, dim3(grid), dim3(256), 0, stream, L, D, in, add ? 1 : 0);
+  return hipGetLastError();
 }
 
 }  // namespace cofactor

@@ -49,6 +49,14 @@ hipError_t launch_count_mask(const uint8_t *mask, uint64_t rows, unsigned long l
 // adds the per-workgroup images partials[slot][wg] into acc[slot] in a fixed order
 hipError_t launch_gram_fold(const double *partials, int nwg, double *acc, hipStream_t stream);
 
+// Dense seam of the multi-GPU path: [N, lin, quad] <-> accumulator image, on the device.
+// n_base: rows counted on the host side (unmasked updates); extra (optional): dense part the state
+// holds on the host, added element-wise.
+hipError_t launch_dense_export(const double *acc, const unsigned long long *kept, double n_base,
+                               const double *extra, int n, int kind, double *out, hipStream_t stream);
+hipError_t launch_dense_import(const double *in, int n, int kind, double *acc, unsigned long long *kept,
+                               hipStream_t stream);
+
 // ---- categorical tables -----------------------------------------------------------------------
 constexpr int MAX_PAIRS = COFACTOR_MAX_CAT * (COFACTOR_MAX_CAT + 1) / 2;
 
@@ -104,6 +112,20 @@ hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const
 // copies the count / sum / pair tables from the old strides to the new ones (code growth)
 hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
                                const CatDevice &Dnew, hipStream_t stream);
+
+// Dictionary-aligned table seam (multi-GPU): re-index tables by a code remap, and the tables as one
+// array of doubles [cnt | s | p] (n_cnt + n_s + n_p values) for a single all-reduce.
+hipError_t launch_cat_remap(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
+                            const CatDevice &Dnew, const int32_t *remap, hipStream_t stream);
+hipError_t launch_cat_tables_export(const CatLayout &L, const CatDevice &D, double *out, hipStream_t stream);
+hipError_t launch_cat_tables_import(const CatLayout &L, const CatDevice &D, const double *in, bool add,
+                                    hipStream_t stream);
+// the dictionary hash (host and device must agree: the host builds aligned dictionaries)
+__host__ __device__ inline unsigned cat_hash_key(int32_t key, int cap) {   // cap: power of two >= 2
+  int lg = 0;
+  while ((1 << lg) < cap) lg++;
+  return ((unsigned)key * 0x9E3779B1u) >> (32 - lg);
+}
 
 // ---- fused dense + categorical kernel for low-cardinality keys (fused.hip) ----------------------
 constexpr int FUSED_MAX_SBLOCKS = 5;    // 32x32 fp32 accumulators one wave may hold (80 of its 168 registers)

@@ -72,10 +72,11 @@ __host__ __device__ constexpr int gram_ring_depth(int n) {
   return n <= 4 ? 5 : (n <= 8 ? 3 : 2);
 }
 
-template <int N, bool ALIGNED>
+template <int N, bool ALIGNED, bool MASKED>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64_t rows,
                                                             double *__restrict__ partials,
-                                                            const uint8_t *__restrict__ mask) {
+                                                            const uint8_t *__restrict__ mask_arg) {
+  const uint8_t *__restrict__ mask = MASKED ? mask_arg : nullptr;   // unfiltered variant: no filter bytes are read
   constexpr int NB = (N + 3) / 4;
   constexpr int NPAIR = NB * (NB + 1) / 2;
   constexpr int NBC = 4 * NB;                     // data columns incl. zero padding to 4*NB
@@ -110,13 +111,12 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   // falls to.
   const uint64_t nfull = rows / GRAM_TILE_ROWS;
   // (the row filter is 4-byte aligned here: launch_gram peels the rows before the first aligned
-  // byte off into a launch of their own; without a filter the same load reads column 0)
-  const uint8_t *mbase = mask ? mask : reinterpret_cast<const uint8_t *>(cols.p[0]);
+  // byte off into a launch of their own)
   auto fetch = [&](float4 (&pre)[LD], unsigned &pre_mask, uint64_t t) {
     const uint64_t r0 = t * GRAM_TILE_ROWS + 4 * (uint64_t)lane;
-    // raw word; park() decides whether it means anything.  (Looking at it here would make the
-    // wave wait for this load right away, and with it for every older load of the ring.)
-    pre_mask = *reinterpret_cast<const unsigned *>(mbase + r0);
+    // raw word; park() looks at it.  (Looking at it here would make the wave wait for this load
+    // right away, and with it for every older load of the ring.)
+    pre_mask = MASKED ? *reinterpret_cast<const unsigned *>(mask + r0) : 0x01010101u;
 #pragma unroll
     for (int i = 0; i < LD; i++) {
       const int col = min(wave + 4 * i, N - 1);   // wave-uniform: q = tid + 256 i, col = q / 64
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
       const int col = wave + 4 * i;
       if (4 * i + 3 < N || col < N) {
         float4 v = pre[i];
-        if (mask) {                               // filtered rows contribute nothing
+        if (MASKED) {                             // filtered rows contribute nothing
           v.x = (pre_mask & 0x000000FFu) ? v.x : 0.f;
           v.y = (pre_mask & 0x0000FF00u) ? v.y : 0.f;
           v.z = (pre_mask & 0x00FF0000u) ? v.z : 0.f;
@@ -275,10 +275,14 @@ hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partia
                     const uint8_t *mask, hipStream_t stream) {
   bool aligned = true;
   for (int k = 0; k < N; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(cols.p[k]) & 15) == 0);
-  if (aligned)
-    hipLaunchKernelGGL((gram_kernel<N, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+  if (aligned && mask)
+    hipLaunchKernelGGL((gram_kernel<N, true, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+  else if (aligned)
+    hipLaunchKernelGGL((gram_kernel<N, true, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+  else if (mask)
+    hipLaunchKernelGGL((gram_kernel<N, false, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
   else
-    hipLaunchKernelGGL((gram_kernel<N, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+    hipLaunchKernelGGL((gram_kernel<N, false, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
   return hipGetLastError();
 }
 
@@ -362,6 +366,64 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
   if ((e = launch_gram_kernel(rest, n, rrows, grid, partials, mask ? mask + head : nullptr, stream)) != hipSuccess) return e;
   if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
   return launch_gram_fold(partials, grid, acc, stream);
+}
+
+// ---- dense seam of the multi-GPU path (SumStateCombine across ranks, sum_state.cpp:25,73-83) ----
+// out[0] = N, out[1..n] = lin, then quad (row-major upper triangle, or the diagonal for NB): the
+// state's dense totals straight from its accumulator image, no host round trip.
+__global__ __launch_bounds__(256) void dense_export_kernel(const double *__restrict__ acc,
+                                                           const unsigned long long *__restrict__ kept,
+                                                           double n_base, const double *__restrict__ extra,
+                                                           int n, int kind, double *__restrict__ out) {
+  const int len = 1 + n + (kind ? n : n * (n + 1) / 2);
+  const int i = threadIdx.x;
+  if (i >= len) return;
+  double v;
+  if (i == 0) v = n_base + (double)*kept;
+  else if (i <= n) v = acc[gram_lin_pos(i - 1, n)];
+  else if (kind) v = acc[gram_quad_pos(i - 1 - n, i - 1 - n, n)];
+  else {
+    int q = i - 1 - n, j = 0;
+    while (q >= n - j) { q -= n - j; j++; }
+    v = acc[gram_quad_pos(j, j + q, n)];
+  }
+  if (extra) v += extra[i];                       // what the state holds on the host (combine, lifted triples)
+  out[i] = v;
+}
+
+// The reverse: the accumulator image becomes exactly the totals in `in` (after the all-reduce).
+__global__ __launch_bounds__(GRAM_ACC_LEN) void dense_import_kernel(const double *__restrict__ in, int n,
+                                                                    int kind, double *__restrict__ acc,
+                                                                    unsigned long long *__restrict__ kept) {
+  __shared__ double img[GRAM_ACC_LEN];
+  const int len = 1 + n + (kind ? n : n * (n + 1) / 2);
+  const int i = threadIdx.x;
+  img[i] = 0.0;
+  __syncthreads();
+  if (i == 0) *kept = (unsigned long long)(in[0] + 0.5);
+  else if (i <= n) img[gram_lin_pos(i - 1, n)] = in[i];
+  else if (i < len) {
+    if (kind) img[gram_quad_pos(i - 1 - n, i - 1 - n, n)] = in[i];
+    else {
+      int q = i - 1 - n, j = 0;
+      while (q >= n - j) { q -= n - j; j++; }
+      img[gram_quad_pos(j, j + q, n)] = in[i];
+    }
+  }
+  __syncthreads();
+  acc[i] = img[i];
+}
+
+hipError_t launch_dense_export(const double *acc, const unsigned long long *kept, double n_base,
+                               const double *extra, int n, int kind, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(dense_export_kernel, dim3(1), dim3(256), 0, stream, acc, kept, n_base, extra, n, kind, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dense_import(const double *in, int n, int kind, double *acc, unsigned long long *kept,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(dense_import_kernel, dim3(1), dim3(GRAM_ACC_LEN), 0, stream, in, n, kind, acc, kept);
+  return hipGetLastError();
 }
 
 }  // namespace cofactor

@@ -7,9 +7,7 @@
 namespace cofactor {
 
 namespace {
-// Cursor over a blob with bounds unknown: the blob is self-describing, so a reader only needs
-// to trust list lengths to be non-negative integers.
-struct Reader {
+struct Reader {               // cursor over a blob whose extent blob_len has validated
   const double *p;
   double next() { return *p++; }
 };
@@ -17,19 +15,25 @@ struct Reader {
 bool small_nonneg_int(double v, double hi) { return v >= 0 && v <= hi && v == std::floor(v); }
 }  // namespace
 
-uint64_t blob_len(const double *b) {
-  if (!b) return 0;
+// Walks the self-describing blob without ever reading at or beyond b[cap]: every list header is
+// checked against what is left.  0 = malformed or truncated.
+uint64_t blob_len(const double *b, uint64_t cap) {
+  if (!b || cap < 4) return 0;
   if (!(b[0] == 0 || b[0] == 1) || !small_nonneg_int(b[1], 1 << 20) ||
       !small_nonneg_int(b[2], 1 << 20))
     return 0;
   const int kind = (int)b[0];
   const uint64_t n = (uint64_t)b[1], m = (uint64_t)b[2];
   uint64_t pos = 4 + n + (kind ? n : tri(n));
+  if (pos > cap) return 0;
   auto skip = [&](uint64_t lists, uint64_t width) {
     for (uint64_t l = 0; l < lists; l++) {
-      double len = b[pos];
+      if (pos >= cap) return false;
+      const double len = b[pos];
       if (!small_nonneg_int(len, 4e15)) return false;
-      pos += 1 + (uint64_t)len * width;
+      const uint64_t body = (uint64_t)len * width;
+      if (body > cap - pos - 1) return false;
+      pos += 1 + body;
     }
     return true;
   };
@@ -41,8 +45,8 @@ uint64_t blob_len(const double *b) {
   return pos;
 }
 
-bool blob_decode(const double *b, ListTriple &t, std::string &err) {
-  if (blob_len(b) == 0) { err = "malformed triple blob header"; return false; }
+bool blob_decode(const double *b, uint64_t cap, ListTriple &t, std::string &err) {
+  if (blob_len(b, cap) == 0) { err = "malformed or truncated triple blob"; return false; }
   Reader r{b};
   t.kind = (int)r.next(); t.n = (int)r.next(); t.m = (int)r.next(); t.N = r.next();
   t.lin.resize(t.n);

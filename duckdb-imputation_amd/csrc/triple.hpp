@@ -24,9 +24,10 @@ struct ListTriple {
   std::vector<std::vector<PairVal>> cat_cat;  // tri(m) (kind 0)
 };
 
-// Walks one blob; returns its length in doubles (0 on a malformed header).
-uint64_t blob_len(const double *b);
-bool blob_decode(const double *b, ListTriple &t, std::string &err);
+// Walks one blob of at most `cap` doubles; returns its length in doubles (0 if it is malformed or
+// does not end within cap: nothing at or beyond b[cap] is read).
+uint64_t blob_len(const double *b, uint64_t cap);
+bool blob_decode(const double *b, uint64_t cap, ListTriple &t, std::string &err);
 void blob_encode(const ListTriple &t, std::vector<double> &out);
 
 // Sparse accumulator (wide: double sums, exact integer counts up to 2^53).

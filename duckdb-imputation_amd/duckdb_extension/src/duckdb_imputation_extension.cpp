@@ -183,6 +183,14 @@ static void RowToBlob(Vector &triple, idx_t row, bool nb, std::vector<double> &b
   auto quad_e = FlatVector::GetData<list_entry_t>(*children[2])[row];
   auto lc_e = FlatVector::GetData<list_entry_t>(*children[3])[row];
   const idx_t n = lin_e.length, m = lc_e.length;
+  // a triple STRUCT that went through SQL may carry lists that do not fit its own n and m: such a
+  // row has no blob (the reference reads past its lists here, sum.cpp:99-106, mul.cpp:57-69)
+  bool consistent = quad_e.length == (nb ? n : n * (n + 1) / 2);
+  if (!nb) {
+    consistent = consistent && FlatVector::GetData<list_entry_t>(*children[4])[row].length == n * m &&
+                 FlatVector::GetData<list_entry_t>(*children[5])[row].length == m * (m + 1) / 2;
+  }
+  if (!consistent) throw InvalidInputException("triple argument: list lengths do not match its lin_agg / lin_cat lengths");
   blob.push_back(nb ? 1 : 0); blob.push_back((double)n); blob.push_back((double)m);
   blob.push_back((double)FlatVector::GetData<int32_t>(*children[0])[row]);
   auto lin = FlatVector::GetData<float>(ListVector::GetEntry(*children[1]));
@@ -342,9 +350,9 @@ static void MultiplyFunction(DataChunk &args, ExpressionState &, Vector &result)
     RowToBlob(args.data[0], i, NB, a);
     RowToBlob(args.data[1], i, NB, b);
     uint64_t need = 0;
-    Check(cofactor_triple_multiply(a.data(), b.data(), nullptr, 0, &need));
+    Check(cofactor_triple_multiply(a.data(), a.size(), b.data(), b.size(), nullptr, 0, &need));
     out.resize(need);
-    Check(cofactor_triple_multiply(a.data(), b.data(), out.data(), need, &need));
+    Check(cofactor_triple_multiply(a.data(), a.size(), b.data(), b.size(), out.data(), need, &need));
     BlobToRow(out.data(), result, i, cur);
   }
 }
@@ -433,9 +441,9 @@ static void LinregTrain(DataChunk &args, ExpressionState &, Vector &result) {
   const int iters = ConstArg<int32_t>(args, 4, "linreg_train");
   const bool variance = ConstArg<bool>(args, 5, "linreg_train"), normalize = ConstArg<bool>(args, 6, "linreg_train");
   uint64_t need = 0;
-  Check(cofactor_linreg_train(blob.data(), label, step, lambda, iters, variance, normalize, nullptr, 0, &need));
+  Check(cofactor_linreg_train(blob.data(), blob.size(), label, step, lambda, iters, variance, normalize, nullptr, 0, &need));
   std::vector<float> params(need);
-  Check(cofactor_linreg_train(blob.data(), label, step, lambda, iters, variance, normalize, params.data(), need, &need));
+  Check(cofactor_linreg_train(blob.data(), blob.size(), label, step, lambda, iters, variance, normalize, params.data(), need, &need));
   EmitFloatList(result, params);
 }
 
@@ -448,9 +456,9 @@ static void LdaTrain(DataChunk &args, ExpressionState &, Vector &result) {
   const float shrinkage = ConstArg<float>(args, 2, "lda_train");
   const bool normalize = ConstArg<bool>(args, 3, "lda_train");
   uint64_t need = 0;
-  Check(cofactor_lda_train(blob.data(), label, shrinkage, normalize, nullptr, 0, &need));
+  Check(cofactor_lda_train(blob.data(), blob.size(), label, shrinkage, normalize, nullptr, 0, &need));
   std::vector<float> params(need);
-  Check(cofactor_lda_train(blob.data(), label, shrinkage, normalize, params.data(), need, &need));
+  Check(cofactor_lda_train(blob.data(), blob.size(), label, shrinkage, normalize, params.data(), need, &need));
   EmitFloatList(result, params);
 }
 

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define COFACTOR_ABI_VERSION 1
+#define COFACTOR_ABI_VERSION 2
 /* sum_to_triple_<x>_<y> is registered for x,y in 0..20 (the reference registers 0..19,
  * duckdb_imputation_extension.cpp:80-84; README.md:136 documents "up to 20"). */
 #define COFACTOR_MAX_NUM 20
@@ -52,7 +52,10 @@ typedef enum {
   COFACTOR_ERR_NO_DEVICE = 2,   /* no usable gfx950 device / HIP runtime error at context create */
   COFACTOR_ERR_HIP = 3,         /* a HIP call failed; message carries hipGetErrorString           */
   COFACTOR_ERR_CAPACITY = 4,    /* output buffer too small; *needed tells how many doubles        */
-  COFACTOR_ERR_UNSUPPORTED = 5  /* shape outside what the device path handles (message says which)*/
+  COFACTOR_ERR_UNSUPPORTED = 5, /* shape outside what the device path handles (message says which)*/
+  COFACTOR_ERR_INTERNAL = 6     /* a device-side invariant broke (a row met a key its dictionary
+                                   pass had not registered); reported by the first call that
+                                   synchronises with the update that caused it                   */
 } cofactor_status;
 
 typedef enum { COFACTOR_TRIPLE = 0, COFACTOR_NB = 1 } cofactor_kind;
@@ -146,12 +149,44 @@ cofactor_status cofactor_agg_finalize(cofactor_agg *agg, double *out, uint64_t c
  * The dense part of the partial triple as ONE device array of doubles
  *   [ N, lin[n], quad[n(n+1)/2 | n] ]            (cofactor_dense_len(n, kind) values)
  * so that a single RCCL all-reduce(sum) over the ranks' arrays is the dense half of
- * SumStateCombine (sum_state.cpp:25,73-83).  export writes the state's current totals into
- * d_out (device memory, caller-owned, e.g. a torch tensor) on the context stream; import
- * REPLACES the state's dense totals by the values in d_in (after the all-reduce). */
+ * SumStateCombine (sum_state.cpp:25,73-83).  Both calls only ENQUEUE a small kernel on the
+ * context stream (cofactor_ctx_stream) and return; nothing is copied to the host.
+ *   export: d_out (device memory, caller-owned, e.g. a torch tensor) receives the state's
+ *           current totals once the stream has passed the call; the collective must be ordered
+ *           after the context stream (run it on that stream, or wait for it).
+ *   import: the state's dense totals BECOME the values in d_in (after the all-reduce).  d_in must
+ *           be complete when the context stream reaches the call and stay valid until it has
+ *           passed it.  Categorical tables are not touched. */
 uint64_t cofactor_dense_len(int n_num, cofactor_kind kind);
 cofactor_status cofactor_agg_export_dense_device(cofactor_agg *agg, double *d_out);
 cofactor_status cofactor_agg_import_dense_device(cofactor_agg *agg, const double *d_in);
+
+/* The categorical half of SumStateCombine across ranks (sum_state.cpp:87-111: merge of the
+ * per-key maps) as dense, dictionary-aligned tables:
+ *   1. every rank lists its keys (cofactor_agg_keys), the lists are all-gathered;
+ *   2. every rank calls cofactor_agg_align_keys with the SAME concatenation of all lists: the
+ *      state's dictionaries become "code = rank of the key in the sorted union" and its count /
+ *      per-key-sum / pair-count tables are re-indexed on the device, so that all ranks now hold
+ *      tables of identical shape and meaning (values the state held on the host under keys are
+ *      folded into the tables);
+ *   3. ONE all-reduce(sum) over the table image [cnt | s | p] (cofactor_agg_tables_len doubles;
+ *      counts are exact integers in doubles), exported and imported on the device like the
+ *      dense part, is the merge.
+ * cofactor_agg_dict_signature tells whether step 1-2 can be skipped: it is non-zero and equal on
+ * all ranks exactly when every rank's dictionaries are still the ones of the last common
+ * alignment (no rank met a new key since).
+ *
+ * keys: two-call protocol (int32 entries); offsets[m+1] delimit the columns, keys ascending.
+ * align_keys: keys[offsets[c] .. offsets[c+1]) = any superset of the state's keys of column c, in
+ * any order, duplicates allowed. */
+cofactor_status cofactor_agg_keys(cofactor_agg *agg, int32_t *out, uint64_t cap, uint64_t *needed,
+                                  uint64_t *offsets);
+cofactor_status cofactor_agg_dict_signature(cofactor_agg *agg, uint64_t *sig);
+cofactor_status cofactor_agg_align_keys(cofactor_agg *agg, const int32_t *keys,
+                                        const uint64_t *offsets);
+uint64_t cofactor_agg_tables_len(cofactor_agg *agg);
+cofactor_status cofactor_agg_export_tables_device(cofactor_agg *agg, double *d_out);
+cofactor_status cofactor_agg_import_tables_device(cofactor_agg *agg, const double *d_in);
 
 /* ---- scalar ring ops on flat triple blobs (host; tiny per-row work) ---------------------------
  * All use the two-call protocol of cofactor_agg_finalize. */
@@ -165,21 +200,25 @@ cofactor_status cofactor_lift_host(const float *const *num, int n_num, const int
 
 /* multiply_triple / multiply_nb_agg — Triple::MultiplyFunction (triple/mul.cpp:19-611),
  * Triple::multiply_nb (triple/mul_nb.cpp:20-268). */
-cofactor_status cofactor_triple_multiply(const double *a, const double *b, double *out,
-                                         uint64_t cap, uint64_t *needed);
+cofactor_status cofactor_triple_multiply(const double *a, uint64_t a_len, const double *b,
+                                         uint64_t b_len, double *out, uint64_t cap,
+                                         uint64_t *needed);
 
 /* Value-level t1 + t2 / t1 - t2 — Triple::sum_triple (imputation/triple/sum.cpp:68-209; also
  * duckdb_extension/src/triple/sum/sum.cpp:319-460), Triple::sum_nb_triple
  * (imputation/triple/sum_nb.cpp:38-83), Triple::subtract_triple (imputation/triple/sub.cpp:
  * 71-217).  On subtract a key missing from `a` is reported via cofactor_last_error() and
  * skipped, as the reference prints and skips (sub.cpp:28-29). */
-cofactor_status cofactor_triple_add(const double *a, const double *b, double *out, uint64_t cap,
-                                    uint64_t *needed);
-cofactor_status cofactor_triple_sub(const double *a, const double *b, double *out, uint64_t cap,
-                                    uint64_t *needed);
+cofactor_status cofactor_triple_add(const double *a, uint64_t a_len, const double *b,
+                                    uint64_t b_len, double *out, uint64_t cap, uint64_t *needed);
+cofactor_status cofactor_triple_sub(const double *a, uint64_t a_len, const double *b,
+                                    uint64_t b_len, double *out, uint64_t cap, uint64_t *needed);
 
-/* Number of doubles in the blob starting at `blob` (walks the lists). */
-uint64_t cofactor_blob_len(const double *blob);
+/* Number of doubles in the blob starting at `blob` (walks the lists); 0 if the blob is malformed
+ * or does not end within `cap` doubles — nothing at or beyond blob[cap] is read.  Every entry
+ * point that takes a blob takes its extent (a_len, b_len, triple_len, offsets[i+1]) and checks
+ * every list header against it before reading. */
+uint64_t cofactor_blob_len(const double *blob, uint64_t cap);
 
 /* ---- consumers of the triple (what one MICE iteration needs) --------------
  * Training is host fp64 over the p x p cofactor matrix (p = 1 + n + #keys, independent of the
@@ -191,7 +230,8 @@ uint64_t cofactor_blob_len(const double *blob);
  * (ML/utils.cpp:176-310).  label = index of the numeric column to predict (0-based).  Output
  * [m, begin[0..m], keys.., intercept, coefficients of the other numeric columns, of every key,
  *  (their means if normalize), (residual std if compute_variance)]  (regression.cpp:313-353). */
-cofactor_status cofactor_linreg_train(const double *triple, int32_t label, float step_size,
+cofactor_status cofactor_linreg_train(const double *triple, uint64_t triple_len, int32_t label,
+                                      float step_size,
                                       float lambda, int32_t max_iterations,
                                       int32_t compute_variance, int32_t normalize, float *out,
                                       uint64_t cap, uint64_t *needed);
@@ -201,7 +241,8 @@ cofactor_status cofactor_linreg_train(const double *triple, int32_t label, float
  * (dgelsd there).  label = index of the key column holding the class.  Output
  * [C, #idx, begin offsets of the other key columns.., their keys.., class keys[C],
  *  coef[C][p], intercept[C], (means[p] if normalize)]  (lda.cpp:335-386). */
-cofactor_status cofactor_lda_train(const double *triple, int32_t label, float shrinkage,
+cofactor_status cofactor_lda_train(const double *triple, uint64_t triple_len, int32_t label,
+                                   float shrinkage,
                                    int32_t normalize, float *out, uint64_t cap, uint64_t *needed);
 
 /* linreg_predict — ML::linreg_impute (regression.cpp:397-508): per row intercept + coef . x +

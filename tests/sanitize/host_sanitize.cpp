@@ -33,9 +33,22 @@ int main(int argc, char **argv) {
   std::string err;
   size_t trained = 0, multiplied = 0;
   for (auto const &b : blobs) {
-    REQUIRE(blob_len(b.data()) == b.size());
+    REQUIRE(blob_len(b.data(), b.size()) == b.size());
     ListTriple t;
-    REQUIRE(blob_decode(b.data(), t, err));
+    REQUIRE(blob_decode(b.data(), b.size(), t, err));
+    // every proper prefix is rejected and never read past (heap copies of exactly that size:
+    // ASan sees any read beyond them); a lying list header as well
+    for (size_t cut : {size_t(0), size_t(3), b.size() / 3, b.size() / 2, b.size() - 1}) {
+      std::vector<double> pre(b.begin(), b.begin() + cut);
+      REQUIRE(blob_len(pre.data(), pre.size()) == 0);
+      ListTriple junk;
+      REQUIRE(!blob_decode(pre.data(), pre.size(), junk, err));
+    }
+    if (t.m > 0) {
+      std::vector<double> lying(b);
+      lying[4 + t.n + (t.kind ? t.n : t.n * (t.n + 1) / 2)] = 1e9;
+      REQUIRE(blob_len(lying.data(), lying.size()) == 0);
+    }
     std::vector<double> again;
     blob_encode(t, again);
     REQUIRE(again == b);
@@ -56,7 +69,7 @@ int main(int argc, char **argv) {
     REQUIRE(diff.N == t.N);
     for (auto const &o : blobs) {                   // every same-kind pair goes through multiply
       ListTriple u, r;
-      REQUIRE(blob_decode(o.data(), u, err));
+      REQUIRE(blob_decode(o.data(), o.size(), u, err));
       if (u.kind != t.kind) continue;
       REQUIRE(multiply(t, u, r, err));
       REQUIRE(r.n == t.n + u.n && r.m == t.m + u.m);
@@ -87,9 +100,9 @@ int main(int argc, char **argv) {
   }
   // malformed headers never get walked
   const double bad[8] = {0, -1, 2, 0, 0, 0, 0, 0};
-  REQUIRE(blob_len(bad) == 0);
+  REQUIRE(blob_len(bad, 8) == 0);
   const double bad2[8] = {0, 0, 1, 5, -3, 0, 0, 0};
-  REQUIRE(blob_len(bad2) == 0);
+  REQUIRE(blob_len(bad2, 8) == 0);
   printf("host_sanitize ok: %zu blobs, %zu products, %zu models\n", blobs.size(), multiplied, trained);
   return 0;
 }

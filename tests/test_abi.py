@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(cofactor_hip.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.cofactor_abi_version() == 1
+    assert lib.cofactor_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -85,10 +85,10 @@ def test_two_call_protocol_and_capacity_error(goldens):
     exp = sorted(goldens["test_sum.py"]["tests"][1]["expected"], key=lambda e: e["row"])
     a, b = dict_to_blob(exp[0]["value"]), dict_to_blob(exp[1]["value"])
     need = C.c_uint64(0)
-    assert lib.cofactor_triple_add(a.ctypes.data, b.ctypes.data, None, 0, C.byref(need)) == cofactor_hip.OK
+    assert lib.cofactor_triple_add(a.ctypes.data, a.size, b.ctypes.data, b.size, None, 0, C.byref(need)) == cofactor_hip.OK
     assert need.value > 4
     small = np.full(4, -1.0)
-    st = lib.cofactor_triple_add(a.ctypes.data, b.ctypes.data, small.ctypes.data, small.size, C.byref(need))
+    st = lib.cofactor_triple_add(a.ctypes.data, a.size, b.ctypes.data, b.size, small.ctypes.data, small.size, C.byref(need))
     assert st == cofactor_hip.ERR_CAPACITY and np.all(small == -1.0)
     assert b"too small" in lib.cofactor_last_error()
 
@@ -107,6 +107,38 @@ def test_malformed_blobs_are_rejected():
         cofactor_hip.add(ok, nb)
 
 
+def test_truncated_and_lying_blobs_are_rejected_without_reading_past_them(goldens):
+    """Every blob-taking entry point gets the blob's extent and checks each list header against
+    it: a blob cut short, or one whose list header claims more entries than there are doubles, is
+    COFACTOR_ERR_INVALID.  The blob sits at the very end of a buffer followed by a NaN canary page
+    that a walk past the end would turn into a different answer."""
+    from triple_fmt import dict_to_blob
+    lib = cofactor_hip.lib()
+    exp = sorted(goldens["test_sum.py"]["tests"][1]["expected"], key=lambda e: e["row"])
+    full = dict_to_blob(exp[0]["value"])
+    assert lib.cofactor_blob_len(full.ctypes.data, full.size) == full.size
+    assert lib.cofactor_blob_len(full.ctypes.data, full.size + 100) == full.size
+    for cut in (0, 3, 4, 7, full.size // 2, full.size - 1):
+        assert lib.cofactor_blob_len(full.ctypes.data, cut) == 0, cut
+        with pytest.raises(cofactor_hip.CofactorError) as e:
+            cofactor_hip.add(full[:cut].copy(), full)
+        assert e.value.status == cofactor_hip.ERR_INVALID
+    n, m = int(full[1]), int(full[2])
+    first_list = 4 + n + n * (n + 1) // 2
+    lying = full.copy()
+    lying[first_list] = 1e6                       # "a million keys" in a blob of a few hundred doubles
+    assert lib.cofactor_blob_len(lying.ctypes.data, lying.size) == 0
+    for fn in (cofactor_hip.add, cofactor_hip.sub, cofactor_hip.multiply):
+        with pytest.raises(cofactor_hip.CofactorError):
+            fn(lying, full)
+        with pytest.raises(cofactor_hip.CofactorError):
+            fn(full, lying)
+    with pytest.raises(cofactor_hip.CofactorError):
+        cofactor_hip.linreg_train(lying, 0)
+    with pytest.raises(cofactor_hip.CofactorError):
+        cofactor_hip.lda_train(full[: full.size - 2].copy(), 0)
+
+
 def test_null_arguments_do_not_crash():
     import ctypes as C
     lib = cofactor_hip.lib()
@@ -114,10 +146,10 @@ def test_null_arguments_do_not_crash():
     assert lib.cofactor_agg_create(None, 1, 0, 0, None) == cofactor_hip.ERR_INVALID
     assert lib.cofactor_agg_finalize(None, None, 0, None) == cofactor_hip.ERR_INVALID
     assert lib.cofactor_agg_combine(None, None) == cofactor_hip.ERR_INVALID
-    assert lib.cofactor_triple_multiply(None, None, None, 0, None) == cofactor_hip.ERR_INVALID
+    assert lib.cofactor_triple_multiply(None, 0, None, 0, None, 0, None) == cofactor_hip.ERR_INVALID
     lib.cofactor_agg_destroy(None)          # no-ops
     lib.cofactor_ctx_destroy(None)
-    assert lib.cofactor_blob_len(None) == 0
+    assert lib.cofactor_blob_len(None, 0) == 0
     assert lib.cofactor_dense_len(20, 0) == 1 + 20 + 210 and lib.cofactor_dense_len(20, 1) == 41
 
 

@@ -137,3 +137,42 @@ def test_unaligned_columns_exact_through_the_tile_ring(ctx, n):
             if j == k or (j + k) % 3 == 0:
                 assert got["quad_agg"][q] == float(int((sel[j] * sel[k]).sum(dtype=torch.int64))), (j, k)
             q += 1
+
+
+def test_20_0_one_billion_rows_exact_on_integer_table(ctx):
+    """C4's table on one GPU (BASELINE.json configs[3]: 1e9 rows x 20 float columns = 80 GB).
+    Whole numbers 0..15 from the shard-reproducible generator (cofactor_hip/synth.py), so every sum
+    is an integer below 2^53 and the HIP result must equal torch's int64 sums exactly: N, all 20
+    lin_agg entries and 70-odd quad_agg entries."""
+    import torch
+    from cofactor_hip import synth
+    rows, n = 1_000_000_000, 20
+    cols, _ = synth.table(torch, 42, n, 0, 0, rows, "cuda", exact=16)
+    torch.cuda.synchronize()
+    agg = ctx.aggregate(n, 0)
+    agg.update_device(cols, [])
+    got = blob_to_dict(agg.finalize())
+    agg.close()
+    assert got["N"] == rows
+    step = 1 << 27
+    lin = [0] * n
+    picked = [(j, k) for j in range(n) for k in range(j, n) if (j * 7 + k) % 5 == 0 or j == k]
+    quad = {p: 0 for p in picked}
+    for a in range(0, rows, step):
+        ints = [c[a:a + step].to(torch.int64) for c in cols]
+        for k in range(n):
+            lin[k] += int(ints[k].sum())
+        for (j, k) in picked:
+            quad[(j, k)] += int((ints[j] * ints[k]).sum())
+        del ints
+    assert got["lin_agg"] == [float(v) for v in lin]
+    assert len(picked) >= 70
+    q = 0
+    for j in range(n):
+        for k in range(j, n):
+            if (j, k) in quad:
+                assert got["quad_agg"][q] == float(quad[(j, k)]), (j, k)
+            q += 1
+    # the first rows of the table are what the host-side generator says they are
+    h, _ = synth.table_np(42, n, 0, 0, 1000, exact=16)
+    assert all(np.array_equal(c[:1000].cpu().numpy(), hc) for c, hc in zip(cols, h))

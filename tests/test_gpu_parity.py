@@ -543,24 +543,103 @@ def test_fused_equals_unfused_large(ctx):
     agg.close()
 
 
-def test_dense_export_import_roundtrip(ctx):
-    """The multi-GPU seam on one GPU: export -> (x2, standing in for a 2-rank all-reduce of equal
-    shards) -> import doubles N, lin and quad and leaves the categorical part alone."""
+@pytest.mark.parametrize("n,m,nb", [(5, 2, False), (20, 0, False), (1, 0, False), (12, 3, True), (7, 0, True)])
+def test_dense_export_import_roundtrip(ctx, n, m, nb):
+    """The dense seam on one GPU: export kernel -> (x2, standing in for a 2-rank all-reduce of
+    equal shards) -> import kernel doubles N, lin and quad and leaves the categorical part alone.
+    Half of the rows come in through a host-side merge (combine), so the export also carries the
+    addends the state holds on the host."""
     import torch
     rng = np.random.default_rng(66)
-    num, cat = int_table(rng, 9000, 5, 2)
-    agg = ctx.aggregate(5, 2)
-    agg.update_host(num, cat)
+    num, cat = int_table(rng, 9000, n, m)
+    kind = cofactor_hip.NB if nb else cofactor_hip.TRIPLE
+    agg, other = ctx.aggregate(n, m, kind), ctx.aggregate(n, m, kind)
+    agg.update_host([c[:4000] for c in num], [c[:4000] for c in cat])
+    other.update_host([c[4000:] for c in num], [c[4000:] for c in cat])
+    agg.combine(other)
+    other.close()
     before = blob_to_dict(agg.finalize())
+    assert before == blob_to_dict(orc.State(orc.WIDE).update(num, cat, nb=nb).finalize())
     buf = torch.zeros(agg.dense_len(), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()                      # torch's fill must not race the library's stream
     agg.export_dense_device(buf.data_ptr())
-    torch.cuda.synchronize()
+    ctx.synchronize()
     host = buf.cpu().numpy()
-    assert host[0] == 9000 and list(host[1:6]) == before["lin_agg"]
+    assert host[0] == 9000 and list(host[1:1 + n]) == before["lin_agg"]
+    assert list(host[1 + n:]) == before["quad_agg"]
     buf *= 2
     torch.cuda.synchronize()
     agg.import_dense_device(buf.data_ptr())
     after = blob_to_dict(agg.finalize())
     assert after["N"] == 18000 and after["quad_agg"] == [2 * v for v in before["quad_agg"]]
-    assert after["lin_cat"] == before["lin_cat"] and after["quad_cat"] == before["quad_cat"]
+    assert after["lin_agg"] == [2 * v for v in before["lin_agg"]]
+    assert after["lin_cat"] == before["lin_cat"]
+    if not nb:
+        assert after["quad_cat"] == before["quad_cat"] and after["quad_num_cat"] == before["quad_num_cat"]
+    agg.close()
+
+
+@pytest.mark.parametrize("n,m,nb,keys", [(3, 2, False, 6), (10, 10, False, 16), (2, 3, False, 70), (0, 2, False, 5),
+                                          (4, 2, True, 9)])
+def test_table_seam_alignment_and_roundtrip(ctx, n, m, nb, keys):
+    """The categorical seam on one GPU: a state is aligned to a global key list that holds keys it
+    never saw (another rank's), keeps its triple, and its table image exported -> x3 -> imported
+    triples every count and per-key sum.  Part of the rows sit on the host side of the state
+    (merged in by combine), so the alignment also folds host-held keys into the tables."""
+    import torch
+    rng = np.random.default_rng(67)
+    rows = 20_000
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [rng.integers(-2, keys - 2, rows).astype(np.int32) for _ in range(m)]
+    kind = cofactor_hip.NB if nb else cofactor_hip.TRIPLE
+    agg, other = ctx.aggregate(n, m, kind), ctx.aggregate(n, m, kind)
+    keep = []                                     # updates are asynchronous: the columns must outlive them
+
+    def d(cols, a, b):
+        keep.append([torch.from_numpy(c[a:b]).cuda() for c in cols])
+        return keep[-1]
+    agg.update_device(d(num, 0, 15_000), d(cat, 0, 15_000))
+    other.update_device(d(num, 15_000, rows), d(cat, 15_000, rows))
+    agg.combine(other)
+    other.close()
+    want = blob_to_dict(orc.State(orc.WIDE).update(num, cat, nb=nb).finalize())
+    assert agg.dict_signature() == 0
+    own, offs = agg.keys()
+    assert [list(own[int(offs[c]):int(offs[c + 1])]) for c in range(m)] == \
+           [sorted(set(c.tolist())) for c in cat]
+    # the "other ranks'" keys: strangers on both sides of every column's range, duplicates, unsorted
+    glob, goffs = [], [0]
+    for c in range(m):
+        mine = own[int(offs[c]):int(offs[c + 1])]
+        lst = np.concatenate([mine[::-1], [1000 + c, -1000 - c, 1000 + c], mine[:3]]).astype(np.int32)
+        glob.append(lst)
+        goffs.append(goffs[-1] + lst.size)
+    agg.align_keys(np.concatenate(glob), np.array(goffs, dtype=np.uint64))
+    sig = agg.dict_signature()
+    assert sig != 0
+    assert blob_to_dict(agg.finalize()) == want          # zero-count keys do not show
+    tlen = int(agg.tables_len())
+    assert tlen > 0
+    buf = torch.zeros(tlen, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    agg.export_tables_device(buf.data_ptr())
+    ctx.synchronize()
+    buf *= 3
+    torch.cuda.synchronize()
+    agg.import_tables_device(buf.data_ptr())
+    got = blob_to_dict(agg.finalize())
+    tripled = lambda lists: [[dict(e, value=3 * e["value"]) for e in l] for l in lists]
+    assert got["lin_cat"] == tripled(want["lin_cat"])
+    if not nb:
+        assert got["quad_num_cat"] == tripled(want["quad_num_cat"])
+        assert got["quad_cat"] == tripled(want["quad_cat"])
+    assert got["lin_agg"] == want["lin_agg"] and got["N"] == want["N"]
+    # more rows with known keys keep the alignment; a new key ends it
+    agg.update_device(d(num, 0, 3000), d(cat, 0, 3000))
+    assert agg.dict_signature() == sig
+    fresh = [torch.full((300,), 7777, dtype=torch.int32, device="cuda") for _ in range(m)]
+    ones = [torch.ones(300, device="cuda") for _ in range(n)]
+    agg.update_device(ones, fresh)
+    assert agg.dict_signature() == 0
+    ctx.synchronize()
     agg.close()

@@ -48,12 +48,24 @@ def test_oracle_matches_reference_goldens(case, mode):
         assert got == want          # exact ==, as the reference's tests do
 
 
+# The reference literals that cannot be derived from their inputs: rows 1 and 2 of the cross-join
+# GROUP BY case of each multiply test file (golden_cases.mul_cross_join says why).
+EXCLUDED = {("test_mul.py", 1, 1), ("test_mul.py", 1, 2), ("test_nb_mul.py", 1, 1), ("test_nb_mul.py", 1, 2)}
+
+
 def test_all_reference_literals_are_covered():
-    """Every expected literal in the fixtures is replayed, except the two documented
-    cross-join rows per multiply file (see golden_cases.mul_cross_join)."""
-    total = sum(len(t["expected"]) for f in _G.values() for t in f["tests"])
-    replayed = 0
-    for _, fn in _CASES:
-        replayed += len(fn(OracleBackend(orc.WIDE)))
-    # the 2 fused_equals_unfused cases replay 2 equalities each without literals
-    assert replayed - 4 == total - 4
+    """60 expected literals sit in the fixtures; 56 are replayed by the cases above and exactly
+    the four named ones are not."""
+    literals = {(fname, ti, e["row"]) for fname, f in _G.items() for ti, t in enumerate(f["tests"])
+                for e in t["expected"]}
+    assert len(literals) == 60
+    assert EXCLUDED <= literals
+    by_literal, self_checks = 0, 0
+    for cid, fn in _CASES:
+        pairs = fn(OracleBackend(orc.WIDE))
+        if cid.endswith("::fused_equals_unfused"):
+            self_checks += len(pairs)            # sum_to == sum(lift): two equalities, no literal
+        else:
+            by_literal += len(pairs)
+    assert by_literal == 56 and by_literal == len(literals) - len(EXCLUDED)
+    assert self_checks == 4
