@@ -97,26 +97,11 @@ def cpu_baseline(num, cat, rows_mt, rows_1t, n, m, nb):
                       "%.2f s wall" % (rows_mt, name, cores, dtm)}
 
 
-def calibrate(torch, device):
-    """What a plain streaming kernel reaches on this GPU: a 4 GiB float4 copy (read + write bytes)
-    and a read-only reduction, both torch built-ins, timed with events."""
-    words = 1 << 30
-    src = torch.empty(words, dtype=torch.float32, device=device).normal_()
-    dst = torch.empty_like(src)
-    out = {}
-    for name, fn, nbytes in (("copy", lambda: dst.copy_(src), 8 * words), ("read", lambda: src.sum(), 4 * words)):
-        fn()
-        torch.cuda.synchronize(device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(device)
-        out[name] = nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del src, dst
-    torch.cuda.empty_cache()
-    return out
+def calibrate(ctx):
+    """What a plain streaming kernel reaches on this GPU (cofactor_ctx_calibrate: float4
+    non-temporal copy and read-only stream over 4 GiB, the access shape of the Gram kernel)."""
+    copy, read = ctx.calibrate(4 << 30, 5)
+    return {"copy": copy, "read": read}
 
 
 def reference_sums(torch, num, pairs):
@@ -263,11 +248,11 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_kernel_ms": avg_ms, "launches": kl, "algorithmic_bytes_per_launch": kbytes}
         if not args.no_calibration:
-            cal = calibrate(torch, device)
+            cal = calibrate(ctx)
             roof["calibrated"] = {"copy_GBs": cal["copy"], "read_GBs": cal["read"],
                                   "frac_of_copy": achieved / cal["copy"], "frac_of_read": achieved / cal["read"],
-                                  "how": "torch float32 copy_ (read + write bytes) and sum() (read bytes) over 4 GiB, "
-                                         "5 repetitions between events"}
+                                  "how": "float4 non-temporal copy (read + written bytes) and read-only stream "
+                                         "over 4 GiB, 5 launches between HIP events (cofactor_ctx_calibrate)"}
         out = {
             "metric": "rows/sec on %s" % fname,
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps,

@@ -19,7 +19,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTE
 SYMBOLS = [
     "cofactor_last_error", "cofactor_abi_version",
     "cofactor_ctx_create", "cofactor_ctx_destroy", "cofactor_ctx_synchronize", "cofactor_ctx_stream",
-    "cofactor_ctx_profile_enable", "cofactor_ctx_profile_read",
+    "cofactor_ctx_profile_enable", "cofactor_ctx_profile_read", "cofactor_ctx_calibrate",
     "cofactor_agg_create", "cofactor_agg_destroy", "cofactor_agg_reset",
     "cofactor_agg_update_device", "cofactor_agg_update_device_masked", "cofactor_agg_update_host",
     "cofactor_agg_update_triples",
@@ -67,6 +67,7 @@ def lib():
         L.cofactor_ctx_stream.restype = vp
         L.cofactor_ctx_profile_enable.argtypes = [vp, C.c_int]
         L.cofactor_ctx_profile_read.argtypes = [vp] + [C.POINTER(C.c_double), pu64] * 3
+        L.cofactor_ctx_calibrate.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.cofactor_agg_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, pp]
         L.cofactor_agg_destroy.argtypes = [vp]
         L.cofactor_agg_destroy.restype = None
@@ -161,6 +162,12 @@ class Context:
         for name, a, b in zip(("gram", "cat", "fused"), ms, ln):
             out[name + "_ms"], out[name + "_launches"] = a.value, b.value
         return out
+
+    def calibrate(self, nbytes=4 << 30, reps=5):
+        """-> (copy GB/s, read GB/s) of a plain float4 streaming kernel on this GPU."""
+        c, r = C.c_double(0), C.c_double(0)
+        _check(lib().cofactor_ctx_calibrate(self._h, nbytes, reps, C.byref(c), C.byref(r)))
+        return c.value, r.value
 
     def aggregate(self, n_num, n_cat, kind=TRIPLE):
         return Aggregate(self, n_num, n_cat, kind)

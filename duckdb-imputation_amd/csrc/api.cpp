@@ -723,6 +723,41 @@ cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms, ui
   return COFACTOR_OK;
 }
 
+cofactor_status cofactor_ctx_calibrate(cofactor_ctx *ctx, uint64_t bytes, int reps, double *copy_gbs,
+                                       double *read_gbs) {
+  if (!ctx || bytes < (1u << 20) || reps < 1) return fail(COFACTOR_ERR_INVALID, "calibrate: bad arguments");
+  CTX_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  void *src = nullptr, *dst = nullptr;
+  HIP_TRY(hipMalloc(&src, bytes));
+  hipError_t e = hipMalloc(&dst, bytes);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e == hipSuccess) e = hipMemsetAsync(src, 0x3c, bytes, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(dst, 0, bytes, ctx->stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  double out[2] = {0, 0};
+  for (int mode = 0; mode < 2 && e == hipSuccess; mode++) {
+    const bool copy = mode == 0;
+    e = launch_calibration(src, dst, bytes, ctx->gram_grid, copy, ctx->stream);     // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = launch_calibration(src, dst, bytes, ctx->gram_grid, copy, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess && ms > 0) out[mode] = (copy ? 2.0 : 1.0) * (double)bytes * reps / (ms * 1e-3) / 1e9;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  if (e != hipSuccess) return hip_fail(e, "calibrate");
+  if (copy_gbs) *copy_gbs = out[0];
+  if (read_gbs) *read_gbs = out[1];
+  return COFACTOR_OK;
+}
+
 cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cofactor_kind kind,
                                     cofactor_agg **out) {
   if (!ctx || !out) return fail(COFACTOR_ERR_INVALID, "ctx/out is null");

@@ -57,6 +57,9 @@ hipError_t launch_dense_export(const double *acc, const unsigned long long *kept
 hipError_t launch_dense_import(const double *in, int n, int kind, double *acc, unsigned long long *kept,
                                hipStream_t stream);
 
+// calibration kernels (cofactor_ctx_calibrate): float4 copy / read-only stream over `bytes`
+hipError_t launch_calibration(const void *src, void *dst, uint64_t bytes, int grid, bool copy, hipStream_t stream);
+
 // ---- categorical tables -----------------------------------------------------------------------
 constexpr int MAX_PAIRS = COFACTOR_MAX_CAT * (COFACTOR_MAX_CAT + 1) / 2;
 

@@ -426,4 +426,46 @@ hipError_t launch_dense_import(const double *in, int n, int kind, double *acc, u
   return hipGetLastError();
 }
 
+// ---- calibration: what a plain streaming kernel reaches on this GPU (bench.py's second roofline) ---
+// float4 per lane, grid-stride, non-temporal, the access shape of gram_kernel's fetch.
+__global__ __launch_bounds__(256) void calib_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
+                                                         uint64_t n4) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i);
+    __builtin_nontemporal_store(b, dst + i + stride);
+    __builtin_nontemporal_store(c, dst + i + 2 * stride);
+    __builtin_nontemporal_store(d, dst + i + 3 * stride);
+  }
+  for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+__global__ __launch_bounds__(256) void calib_read_kernel(const f32x4 *__restrict__ src, float *__restrict__ out,
+                                                         uint64_t n4) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    s0 += __builtin_nontemporal_load(src + i);
+    s1 += __builtin_nontemporal_load(src + i + stride);
+    s2 += __builtin_nontemporal_load(src + i + 2 * stride);
+    s3 += __builtin_nontemporal_load(src + i + 3 * stride);
+  }
+  for (; i < n4; i += stride) s0 += __builtin_nontemporal_load(src + i);
+  const f32x4 s = (s0 + s1) + (s2 + s3);
+  const float v = (s[0] + s[1]) + (s[2] + s[3]);
+  if (v == 12345.678f) out[0] = v;                 // keeps the loads alive; practically never true
+}
+
+hipError_t launch_calibration(const void *src, void *dst, uint64_t bytes, int grid, bool copy, hipStream_t stream) {
+  const uint64_t n4 = bytes / 16;
+  if (copy)
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4 *)src, (f32x4 *)dst, n4);
+  else
+    hipLaunchKernelGGL(calib_read_kernel, dim3(grid), dim3(256), 0, stream, (const f32x4 *)src, (float *)dst, n4);
+  return hipGetLastError();
+}
+
 }  // namespace cofactor

@@ -86,6 +86,12 @@ cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms,
                                           uint64_t *cat_launches, double *fused_ms,
                                           uint64_t *fused_launches);
 
+/* Measurement support (bench.py's calibrated roofline, SURVEY.md §8d "report both"): GB/s a plain
+ * float4 streaming kernel reaches on this GPU over a scratch buffer of `bytes` bytes, `reps`
+ * launches between HIP events: copy (read + written bytes counted) and read-only. */
+cofactor_status cofactor_ctx_calibrate(cofactor_ctx *ctx, uint64_t bytes, int reps, double *copy_gbs,
+                                       double *read_gbs);
+
 /* ---- aggregate state ------------------------------------------------------------------------
  * Replaces Triple::SumState + StateFunction::Initialize/Destroy
  * (duckdb_extension/src/include/triple/sum/sum_state.h:14-57).  n/m are what the reference
