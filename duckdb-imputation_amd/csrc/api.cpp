@@ -67,6 +67,8 @@ struct cofactor_ctx {
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev, fused_ev;
   bool allow_fused = true;      // COFACTOR_NO_FUSED=1 forces the two-kernel path
+  int fused_pref = 0;           // COFACTOR_FUSED=1 / 2: only fused_kernel / only fused2_kernel (A/B runs);
+                                // default: fused_kernel where it applies (faster at 10_10), else fused2_kernel
   bool allow_optimistic = true; // COFACTOR_NO_OPTIMISTIC=1: always run the dictionary pass first
   unsigned *skip = nullptr;     // optimistic fused pass: [count, tile ids...]
   size_t skip_bytes = 0;
@@ -340,26 +342,52 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
   a->dev_dirty = true;
   cofactor_ctx *ctx = a->ctx;
   hipStream_t st = ctx->stream;
+  // one fused2 launch takes a bounded number of rows (its int32 pair accumulators): longer updates
+  // go in pieces of whole tiles
+  {
+    const uint64_t piece = fused2_max_rows(ctx->cus) / FUSED_TILE_ROWS * FUSED_TILE_ROWS;
+    if (a->m > 0 && rows > piece) {
+      for (uint64_t off = 0; off < rows; off += piece) {
+        NumCols pn = num;
+        CatCols pc = cat;
+        for (int k = 0; k < a->n; k++) pn.p[k] = num.p[k] + off;
+        for (int c = 0; c < a->m; c++) pc.p[c] = cat.p[c] + off;
+        cofactor_status s = update_device_impl(a, pn, pc, std::min(piece, rows - off), allow_optimistic,
+                                               mask ? mask + off : nullptr);
+        if (s != COFACTOR_OK) return s;
+      }
+      return COFACTOR_OK;
+    }
+  }
   bool aligned = rows >= FUSED_TILE_ROWS &&         // the fused kernel wants whole tiles of aligned columns
                  (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
   for (int k = 0; k < a->n; k++) aligned = aligned && (reinterpret_cast<uintptr_t>(num.p[k]) & 15) == 0;
   for (int c = 0; c < a->m; c++) aligned = aligned && (reinterpret_cast<uintptr_t>(cat.p[c]) & 15) == 0;
   const uint64_t main_rows = rows - rows % FUSED_TILE_ROWS;
+  // which one-pass kernel: fused_kernel (three teams, LDS-atomic pair counts) where it applies,
+  // fused2_kernel (LDS-DMA ring, everything on MFMA) for what it does not take: NB aggregates, n = 0
+  bool v1 = false;
+  auto fused_fits = [&]() {
+    const bool ok1 = ctx->fused_pref != 2 && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
+    const bool ok2 = ctx->fused_pref != 1 && fused2_applicable(a->L, a->nkeys_host, mask != nullptr, ctx->lds_max);
+    v1 = ok1;
+    return ok1 || ok2;
+  };
 
   // Optimistic mode: when every column already has a dictionary that fits the fused kernel, skip
-  // the dictionary pass; the kernel leaves out (and lists) the tiles that meet an unknown key, and
-  // only those are redone below after a dictionary pass over them.
+  // the dictionary pass; the kernel leaves out (and lists) the row blocks that meet an unknown key,
+  // and only those are redone below after a dictionary pass over them.
   bool optimistic = allow_optimistic && ctx->allow_fused && ctx->allow_optimistic && a->m > 0 && aligned &&
                     a->cat_ready;
   if (optimistic) {
     for (int c = 0; c < a->m; c++) optimistic = optimistic && a->nkeys_host[c] >= 1;
-    optimistic = optimistic && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
+    optimistic = optimistic && fused_fits();
   }
   bool fused = optimistic;
   if (a->m > 0 && !optimistic) {
     cofactor_status s = cat_dictionaries(a, cat, rows);
     if (s != COFACTOR_OK) return s;
-    fused = ctx->allow_fused && aligned && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
+    fused = ctx->allow_fused && aligned && fused_fits();
   }
 #ifdef COFACTOR_DEV_ABLATE
   if (a->m > 0) {
@@ -370,6 +398,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
 #endif
   uint64_t done = 0;
   unsigned skipped = 0;
+  const uint64_t skip_unit = v1 ? FUSED_TILE_ROWS : FUSED2_SKIP_UNIT;   // rows per entry of the skip list
   if (fused) {                                    // one pass: dense + categorical
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profiling) {
@@ -377,7 +406,8 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       HIP_TRY(hipEventCreate(&e1));
       ctx->fused_ev.emplace_back(e0, e1);
     }
-    const int grid = fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows);
+    const int grid = v1 ? fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows)
+                        : fused2_grid(ctx->cus, ctx->gram_grid, main_rows);
     const size_t slab = fused_slab_bytes(a->L, grid);
     if (slab > ctx->pair_slab_bytes) {            // grow the per-workgroup pair slabs
       HIP_TRY(hipStreamSynchronize(st));
@@ -389,7 +419,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
     }
     unsigned *skip = nullptr;
     if (optimistic) {
-      const size_t need = (main_rows / FUSED_TILE_ROWS + 1) * sizeof(unsigned);
+      const size_t need = (main_rows / skip_unit + 1) * sizeof(unsigned);
       if (need > ctx->skip_bytes) {
         HIP_TRY(hipStreamSynchronize(st));
         (void)hipFree(ctx->skip);
@@ -401,21 +431,27 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       skip = ctx->skip;
       HIP_TRY(hipMemsetAsync(skip, 0, sizeof(unsigned), st));
     }
-    HIP_TRY(launch_fused(num, cat, main_rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, skip,
-                         a->d_acc, st, e0, e1, mask, a->d_kept));
+    if (v1)
+      HIP_TRY(launch_fused(num, cat, main_rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, skip,
+                           a->d_acc, st, e0, e1, mask, a->d_kept));
+    else
+      HIP_TRY(launch_fused2(num, cat, main_rows, a->L, a->D, grid, ctx->lds_max, ctx->partials, ctx->pair_slabs,
+                            skip, a->d_acc, st, e0, e1, mask, a->d_kept));
     done = main_rows;
     if (optimistic) {
       HIP_TRY(hipMemcpyAsync(&skipped, skip, sizeof(unsigned), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
     }
   }
-  if (skipped > 0) {                              // redo the left-out tiles, dictionary pass included
-    const uint64_t trows = (uint64_t)skipped * FUSED_TILE_ROWS;
+  if (skipped > 0) {                              // redo the left-out row blocks, dictionary pass included
+    const uint64_t trows = (uint64_t)skipped * skip_unit;
     unsigned *temp = nullptr;
     HIP_TRY(hipMalloc((void **)&temp, sizeof(unsigned) * trows * (size_t)(a->n + a->m) + (mask ? trows : 0)));
     uint8_t *tmask = mask ? reinterpret_cast<uint8_t *>(temp + trows * (size_t)(a->n + a->m)) : nullptr;
-    hipError_t ge = launch_gather_tiles(num, cat, a->n, a->m, ctx->skip + 1, skipped, temp, trows, st, mask, tmask);
-    cofactor_status s = ge == hipSuccess ? COFACTOR_OK : hip_fail(ge, "launch_gather_tiles");
+    hipError_t ge = v1 ? launch_gather_tiles(num, cat, a->n, a->m, ctx->skip + 1, skipped, temp, trows, st, mask, tmask)
+                       : launch_gather_units(num, cat, a->n, a->m, (int)skip_unit, ctx->skip + 1, skipped, temp, trows,
+                                             st, mask, tmask);
+    cofactor_status s = ge == hipSuccess ? COFACTOR_OK : hip_fail(ge, "gather of the left-out rows");
     if (s == COFACTOR_OK) {
       NumCols gnum{};
       CatCols gcat{};
@@ -665,6 +701,7 @@ cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   if (ctx->lds_budget > ctx->lds_max) ctx->lds_budget = ctx->lds_max;
   ctx->allow_fused = env_long("COFACTOR_NO_FUSED", 0) == 0;
   ctx->allow_optimistic = env_long("COFACTOR_NO_OPTIMISTIC", 0) == 0;
+  ctx->fused_pref = (int)env_long("COFACTOR_FUSED", 0);
   HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)ctx->gram_grid * GRAM_ACC_LEN));
   *out = ctx.release();
   return COFACTOR_OK;

@@ -155,6 +155,24 @@ hipError_t launch_gather_tiles(const NumCols &num, const CatCols &cat, int n, in
                                unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream,
                                const uint8_t *mask = nullptr, uint8_t *temp_mask = nullptr);
 
+// ---- fused2.hip: the one-pass kernel for low-cardinality keys (<= 16 keys per column, <= 10 key
+// columns, triple and NB kinds, n >= 0); whole 256-row tiles of 16-byte aligned columns ------------
+bool fused2_applicable(const CatLayout &L, const int32_t *nkeys, bool masked, size_t lds_limit);
+int fused2_grid(int cus, int partials_cap_wgs, uint64_t rows);
+// rows one launch may take: the int32 pair accumulators of a wave hold 2^31 / 4096 rows
+inline uint64_t fused2_max_rows(int grid) { return (uint64_t)grid * 8000ull * FUSED_TILE_ROWS; }
+constexpr int FUSED2_SKIP_UNIT = 64;    // rows per entry of the optimistic pass's skip list
+// skip != nullptr (optimistic mode): skip[0] counts and skip[1..] lists the 64-row blocks that met
+// an unknown key and were left out entirely.
+hipError_t launch_fused2(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
+                         const CatDevice &D, int grid, size_t lds_limit, double *partials, unsigned *pair_slabs,
+                         unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                         hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr,
+                         unsigned long long *kept = nullptr);
+hipError_t launch_gather_units(const NumCols &num, const CatCols &cat, int n, int m, int unit, const unsigned *list,
+                               unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream,
+                               const uint8_t *mask = nullptr, uint8_t *temp_mask = nullptr);
+
 // ---- per-row predictors (predict.hip) ------------------------------------------------------------
 // out = W . [1, x_0..x_{F-1}, onehot(keys of the M key columns)] per class; argmax picks the class
 // (labels == nullptr: its index), otherwise class 0's value (+ noise) is written as a float.

@@ -643,3 +643,52 @@ def test_table_seam_alignment_and_roundtrip(ctx, n, m, nb, keys):
     assert agg.dict_signature() == 0
     ctx.synchronize()
     agg.close()
+
+
+@pytest.mark.parametrize("pref", ["1", "2"])
+@pytest.mark.parametrize("n,m,nb,keys", [(10, 10, False, 16), (3, 2, False, 7), (0, 3, False, 16), (5, 1, False, 3),
+                                          (20, 4, False, 9), (12, 7, False, 16), (16, 6, False, 12), (4, 3, True, 16),
+                                          (0, 2, True, 5), (20, 10, True, 16), (7, 9, False, 2)])
+def test_both_one_pass_kernels_exact(monkeypatch, pref, n, m, nb, keys):
+    """COFACTOR_FUSED=1 pins fused_kernel (three teams), =2 fused2_kernel (LDS-DMA ring, one-hot
+    MFMAs); shapes a kernel does not take go through the two-kernel path.  Integer-valued table,
+    ragged row count, keys below zero (hash probe instead of the byte table) in every other column,
+    plain and filtered updates, then a second update in optimistic mode that brings a new key:
+    every count and sum must equal the oracle's exactly."""
+    import torch
+    monkeypatch.setenv("COFACTOR_FUSED", pref)
+    c2 = cofactor_hip.Context(0)
+    rng = np.random.default_rng(1000 + 7 * n + m)
+    rows = 70_000 + 37
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [(rng.integers(0, keys, rows) - (3 if c % 2 else 0)).astype(np.int32) for c in range(m)]
+    mask = (rng.random(rows) < 0.6).astype(np.uint8)
+    kind = cofactor_hip.NB if nb else cofactor_hip.TRIPLE
+    dn = [torch.from_numpy(c).cuda() for c in num]
+    dc = [torch.from_numpy(c).cuda() for c in cat]
+    dm = torch.from_numpy(mask).cuda()
+    torch.cuda.synchronize()
+    for use_mask in (False, True):
+        agg = c2.aggregate(n, m, kind)
+        if use_mask:
+            agg.update_device_masked(dn, dc, dm)
+            sel = mask.astype(bool)
+        else:
+            agg.update_device(dn, dc)
+            sel = np.ones(rows, dtype=bool)
+        want = orc.State(orc.WIDE).update([c[sel] for c in num], [c[sel] for c in cat], nb=nb)
+        assert blob_to_dict(agg.finalize()) == blob_to_dict(want.finalize()), use_mask
+        # second batch, dictionaries known (optimistic pass), one new key in the middle of it
+        cat2 = [c.copy() for c in cat]
+        if keys < 16:
+            cat2[0][40_000:40_003] = 12345
+        dc2 = [torch.from_numpy(c).cuda() for c in cat2]
+        torch.cuda.synchronize()
+        if use_mask:
+            agg.update_device_masked(dn, dc2, dm)
+        else:
+            agg.update_device(dn, dc2)
+        want.update([c[sel] for c in num], [c[sel] for c in cat2], nb=nb)
+        assert blob_to_dict(agg.finalize()) == blob_to_dict(want.finalize()), ("second", use_mask)
+        agg.close()
+    c2.close()
