@@ -28,6 +28,11 @@ SYMBOLS = [
     "cofactor_agg_keys", "cofactor_agg_dict_signature", "cofactor_agg_align_keys",
     "cofactor_agg_tables_len", "cofactor_agg_export_tables_device", "cofactor_agg_import_tables_device",
     "cofactor_lift_host", "cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub",
+    "cofactor_lift_device", "cofactor_agg_update_tvec_device", "cofactor_multiply_device",
+    "cofactor_lift_host_tvec", "cofactor_agg_update_tvec_host", "cofactor_multiply_host",
+    "cofactor_groups_create", "cofactor_groups_destroy", "cofactor_groups_update_device",
+    "cofactor_groups_update_host", "cofactor_groups_count", "cofactor_groups_combine",
+    "cofactor_groups_finalize", "cofactor_groups_to_tvec",
     "cofactor_blob_len",
     "cofactor_linreg_train", "cofactor_lda_train",
     "cofactor_linreg_predict_device", "cofactor_lda_predict_device",

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -13,11 +14,13 @@
 
 #include "device.hpp"
 #include "ml.hpp"
+#include "state.hpp"
 #include "triple.hpp"
 
 using namespace cofactor;
 
-namespace {
+namespace cofactor {
+namespace detail {
 
 thread_local std::string g_err;
 
@@ -28,11 +31,6 @@ cofactor_status fail(cofactor_status st, const std::string &msg) {
 cofactor_status hip_fail(hipError_t e, const char *what) {
   return fail(COFACTOR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
-#define HIP_TRY(expr)                                        \
-  do {                                                       \
-    hipError_t e_ = (expr);                                  \
-    if (e_ != hipSuccess) return hip_fail(e_, #expr);        \
-  } while (0)
 
 long env_long(const char *name, long dflt) {
   const char *v = std::getenv(name);
@@ -48,81 +46,13 @@ int next_pow2(int v) {
   return p;
 }
 
-}  // namespace
+}  // namespace detail
+}  // namespace cofactor
 
-struct cofactor_ctx {
-  // Aggregates of one context share its stream and scratch buffers (partials, pair slabs, skip
-  // list): every entry point that enqueues device work holds this lock for its whole sequence.
-  std::recursive_mutex mu;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int cus = 0;
-  int gram_grid = 0;            // workgroups of the Gram kernel
-  int cat_grid = 0;             // workgroups of the categorical kernel
-  size_t lds_budget = 0;        // bytes of LDS one categorical workgroup may claim
-  double *partials = nullptr;   // gram_grid * GRAM_ACC_LEN doubles
-  unsigned *pair_slabs = nullptr;   // fused kernel: one u32 pair table per workgroup
-  size_t pair_slab_bytes = 0;
-  // optional HIP-event timing of the two streaming kernels (cofactor_ctx_profile_*)
-  bool profiling = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev, fused_ev;
-  bool allow_fused = true;      // COFACTOR_NO_FUSED=1 forces the two-kernel path
-  int fused_pref = 0;           // COFACTOR_FUSED=1 / 2: only fused_kernel / only fused2_kernel (A/B runs);
-                                // default: fused_kernel where it applies (faster at 10_10), else fused2_kernel
-  bool allow_optimistic = true; // COFACTOR_NO_OPTIMISTIC=1: always run the dictionary pass first
-  unsigned *skip = nullptr;     // optimistic fused pass: [count, tile ids...]
-  size_t skip_bytes = 0;
-  size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
-};
+using namespace cofactor::detail;
 
-#define CTX_LOCK(ctxp) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxp)->mu)
-
-struct cofactor_agg {
-  cofactor_ctx *ctx = nullptr;
-  int n = 0, m = 0, kind = 0;
-  HostTriple host;              // everything merged in on the host (combine, lifted triples, import)
-  double dev_rows = 0;          // rows (of unmasked updates) whose contributions sit in the device tables
-  unsigned long long *d_kept = nullptr;   // device counter: rows kept by masked updates
-  bool dev_dirty = false;       // the device tables hold something
-  double *d_acc = nullptr;      // dense accumulator image (GRAM_ACC_LEN doubles)
-  // categorical device state
-  bool cat_ready = false;
-  bool cat_check_pending = false;
-  int32_t nkeys_host[COFACTOR_MAX_CAT] = {0};
-  // finalize's two-call protocol: the blob of the size query is kept for the fill call
-  std::vector<double> blob_cache;
-  bool blob_cache_valid = false;
-  CatLayout L{};
-  CatDevice D{};
-  // host staging for update_host (pinned) and its device mirror, both double-buffered: while
-  // buffer b is on its way to the device (copy + kernels, asynchronous), chunks land in b ^ 1
-  uint64_t stage_cap = 0, stage_rows = 0;
-  int stage_buf = 0;
-  hipEvent_t stage_ev[2] = {nullptr, nullptr};
-  bool stage_busy[2] = {false, false};
-  float *h_num = nullptr;
-  int32_t *h_cat = nullptr;
-  float *d_num = nullptr;
-  int32_t *d_cat = nullptr;
-  // dense seam: the host-side dense addends on their way to the export kernel
-  double *d_host_dense = nullptr;
-  std::vector<double> host_dense_stage;
-  // table seam: signature of the key lists the dictionaries were last aligned to (0 = the
-  // dictionaries have changed since, or were never aligned)
-  uint64_t dict_sig = 0;
-};
-
-namespace {
-
-struct DeviceGuard {
-  int prev = -1;
-  explicit DeviceGuard(int dev) {
-    (void)hipGetDevice(&prev);
-    if (prev != dev) (void)hipSetDevice(dev);
-    else prev = -1;
-  }
-  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
+namespace cofactor {
+namespace detail {
 
 void cat_free(CatDevice &D) {
   (void)hipFree(D.ht_slot); (void)hipFree(D.ht_code); (void)hipFree(D.nkeys); (void)hipFree(D.flags);
@@ -211,13 +141,18 @@ cofactor_status cat_prepare(cofactor_agg *a) {
 // and code-indexed tables when a column outgrew them.  Leaves the per-column key counts in
 // a->nkeys_host.
 cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t rows) {
+  return cat_dictionaries_with(a, [&]() { return launch_cat_insert(cat, rows, a->L, a->D, a->ctx->stream); });
+}
+
+// the same with any kernel that inserts a batch's keys into a->D's dictionaries (a->L's geometry)
+cofactor_status cat_dictionaries_with(cofactor_agg *a, const std::function<hipError_t()> &insert) {
   cofactor_status s = cat_prepare(a);
   if (s != COFACTOR_OK) return s;
   hipStream_t st = a->ctx->stream;
   int32_t counters[COFACTOR_MAX_CAT + 4];
   for (int attempt = 0;; attempt++) {
     HIP_TRY(hipMemsetAsync(a->D.flags, 0, sizeof(int32_t), st));   // [0] only; [1] is sticky
-    HIP_TRY(launch_cat_insert(cat, rows, a->L, a->D, st));
+    HIP_TRY(insert());
     HIP_TRY(hipMemcpyAsync(counters + COFACTOR_MAX_CAT, a->D.flags, sizeof(int32_t) * 4,
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -670,7 +605,8 @@ cofactor_status emit_blob(const std::vector<double> &blob, double *out, uint64_t
   return COFACTOR_OK;
 }
 
-}  // namespace
+}  // namespace detail
+}  // namespace cofactor
 
 extern "C" {
 
@@ -715,6 +651,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->partials);
   (void)hipFree(ctx->pair_slabs);
   (void)hipFree(ctx->skip);
+  (void)hipFree(ctx->ring_red);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

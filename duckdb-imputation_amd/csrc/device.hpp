@@ -130,6 +130,40 @@ __host__ __device__ inline unsigned cat_hash_key(int32_t key, int cap) {   // ca
   return ((unsigned)key * 0x9E3779B1u) >> (32 - lg);
 }
 
+// ---- dictionary primitives shared by the kernels that work on key lists (cat.hip, ring.hip) ------------
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long cat_pack_key(int32_t key) {
+  return (1ull << 32) | (unsigned long long)(unsigned)key;
+}
+// inserts `key` into the column's open-addressing table (cap = power of two); flags[0] = 1 when full
+__device__ __forceinline__ void cat_dict_insert(unsigned long long *slots, int cap, int32_t key, int32_t *flags) {
+  const unsigned long long want = cat_pack_key(key);
+  unsigned h = cat_hash_key(key, cap);
+  for (int probe = 0; probe < cap; probe++) {
+    const unsigned long long cur = slots[h];
+    if (cur == want) return;
+    if (cur == 0ull) {
+      const unsigned long long old = atomicCAS(&slots[h], 0ull, want);
+      if (old == 0ull || old == want) return;
+    }
+    h = (h + 1) & (cap - 1);
+  }
+  flags[0] = 1;
+}
+// code of a key (-1 if the dictionary does not hold it)
+__device__ __forceinline__ int cat_lookup_code(const unsigned long long *slots, const int32_t *codes, int cap, int32_t key) {
+  const unsigned long long want = cat_pack_key(key);
+  unsigned h = cat_hash_key(key, cap);
+  for (int probe = 0; probe < cap; probe++) {
+    const unsigned long long cur = slots[h];
+    if (cur == want) return codes[h];
+    if (cur == 0ull) return -1;
+    h = (h + 1) & (cap - 1);
+  }
+  return -1;
+}
+#endif
+
 // ---- fused dense + categorical kernel for low-cardinality keys (fused.hip) ----------------------
 constexpr int FUSED_MAX_SBLOCKS = 5;    // 32x32 fp32 accumulators one wave may hold (80 of its 168 registers)
 // True when the shape can run on fused_kernel: triple kind, n >= 1, m >= 1, every column has at

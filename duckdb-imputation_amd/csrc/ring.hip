@@ -1,0 +1,597 @@
+// Batched ring operations on vectors of triples and the GROUP BY state pool:
+//   lift_kernel            to_cofactor / to_nb_agg       (triple/lift.cpp:15-243, lift_to_nb_agg.cpp:13-136)
+//   tvec_dense_kernel      sum_triple, dense children    (triple/sum/sum.cpp:86-149)
+//   tvec_keys_kernel       sum_triple, key lists          (triple/sum/sum.cpp:197-260)
+//   mul_*_kernel           multiply_triple / _nb_agg      (triple/mul.cpp:19-611, mul_nb.cpp:20-268)
+//   groups_*_kernel        sum_to_triple ... GROUP BY g   (per-row state pointers, sum_no_lift.cpp:84-214)
+// A vector of triples is held exactly as DuckDB holds the reference's result STRUCT (cofactor_tvec in
+// include/cofactor_hip.h): one array per leaf, (offset, length) pairs per list level.
+#include "ring.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+namespace cofactor {
+
+namespace {
+
+__host__ __device__ inline int tri_i(int k) { return k * (k + 1) / 2; }
+__host__ __device__ inline int pair_q(int c1, int c2, int m) { return c1 * m - c1 * (c1 - 1) / 2 + (c2 - c1); }
+// q -> (c1, c2), c1 <= c2, of an m-column upper triangle
+__device__ inline void pair_decode(int q, int m, int &c1, int &c2) {
+  c1 = 0;
+  while (q >= m - c1) { q -= m - c1; c1++; }
+  c2 = c1 + q;
+}
+
+// ---- to_cofactor ---------------------------------------------------------------------------------
+// One thread per written element; every array is written front to back, fully coalesced.
+__global__ __launch_bounds__(256) void lift_kernel(NumCols num, CatCols cat, int n, int m, int kind, uint64_t rows,
+                                                   cofactor_tvec o) {
+  const int T = kind ? n : tri_i(n), Tm = kind ? 0 : tri_i(m), nm = kind ? 0 : n * m;
+  // work items per row: 1 N + n lin + T quad + 5 outer/row entries + m lc (sub, key, val) + nm nc + Tm cc
+  const uint64_t per_row = 1 + (uint64_t)n + T + 5 + m + nm + Tm;
+  const uint64_t total = rows * per_row;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (uint64_t)gridDim.x * blockDim.x) {
+    // arrays in turn, each of length rows * (its items per row)
+    uint64_t u = w;
+    if (u < rows) { o.N[u] = 1; continue; }
+    u -= rows;
+    if (u < rows * n) { const uint64_t i = u / n; const int k = (int)(u % n); o.lin[u] = num.p[k][i]; continue; }
+    u -= rows * n;
+    if (u < rows * T) {
+      const uint64_t i = u / T; int q = (int)(u % T), j = 0, k;
+      if (kind) { j = k = q; }
+      else { while (q >= n - j) { q -= n - j; j++; } k = j + q; }
+      o.quad[u] = num.p[j][i] * num.p[k][i];        // float product, as the reference stores it (lift.cpp:119-136)
+      continue;
+    }
+    u -= rows * T;
+    if (u < rows) { o.lin_e[2 * u] = u * n; o.lin_e[2 * u + 1] = n; continue; }
+    u -= rows;
+    if (u < rows) { o.quad_e[2 * u] = u * T; o.quad_e[2 * u + 1] = T; continue; }
+    u -= rows;
+    if (u < rows) { if (o.lc_outer) { o.lc_outer[2 * u] = u * m; o.lc_outer[2 * u + 1] = m; } continue; }
+    u -= rows;
+    if (u < rows) { if (!kind && o.nc_outer) { o.nc_outer[2 * u] = u * nm; o.nc_outer[2 * u + 1] = nm; } continue; }
+    u -= rows;
+    if (u < rows) { if (!kind && o.cc_outer) { o.cc_outer[2 * u] = u * Tm; o.cc_outer[2 * u + 1] = Tm; } continue; }
+    u -= rows;
+    if (u < rows * m) {                              // lin_cat: [{key, 1}] per key column (lift.cpp:94-105)
+      const uint64_t i = u / m; const int c = (int)(u % m);
+      o.lc_sub[2 * u] = u; o.lc_sub[2 * u + 1] = 1; o.lc_key[u] = cat.p[c][i]; o.lc_val[u] = 1.f;
+      continue;
+    }
+    u -= rows * m;
+    if (u < rows * nm) {                             // quad_num_cat[(j m + c)] = [{key_c, x_j}] (lift.cpp:156-176)
+      const uint64_t i = u / nm; const int s = (int)(u % nm), j = s / m, c = s % m;
+      o.nc_sub[2 * u] = u; o.nc_sub[2 * u + 1] = 1; o.nc_key[u] = cat.p[c][i]; o.nc_val[u] = num.p[j][i];
+      continue;
+    }
+    u -= rows * nm;
+    {                                               // quad_cat[(c1, c2 >= c1)] = [{k1, k2, 1}] (lift.cpp:199-219)
+      const uint64_t i = u / Tm; int c1, c2;
+      pair_decode((int)(u % Tm), m, c1, c2);
+      o.cc_sub[2 * u] = u; o.cc_sub[2 * u + 1] = 1;
+      o.cc_key1[u] = cat.p[c1][i]; o.cc_key2[u] = cat.p[c2][i]; o.cc_val[u] = 1.f;
+    }
+  }
+}
+
+// ---- sum_triple: dense children -------------------------------------------------------------------
+// acc[0] += sum N, acc[1 + k] += sum lin[.][k], acc[1 + n + q] += sum quad[.][q].  A block walks a
+// chunk of rows, thread k owns column k (a row's D = 1 + n + T values are contiguous: coalesced).
+__global__ __launch_bounds__(256) void tvec_dense_kernel(cofactor_tvec v, int T, double *__restrict__ acc) {
+  const int n = v.n, D = 1 + n + T, k = threadIdx.x;
+  if (k >= D) return;
+  const uint64_t per = (v.count + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = min(v.count, lo + per);
+  double s = 0;
+  for (uint64_t i = lo; i < hi; i++) {
+    float x;
+    if (k == 0) x = (float)v.N[i];
+    else if (k <= n) x = v.lin[v.lin_e[2 * i] + (k - 1)];
+    else x = v.quad[v.quad_e[2 * i] + (k - 1 - n)];
+    s += (double)x;
+  }
+  if (lo < hi) unsafeAtomicAdd(&acc[k], s);
+}
+
+// acc image of the aggregate (gram.hip layout) += the reduced dense vector; kept += N
+__global__ void tvec_dense_apply_kernel(const double *__restrict__ red, int n, int kind, double *__restrict__ acc,
+                                        unsigned long long *__restrict__ kept) {
+  const int T = kind ? n : tri_i(n), i = threadIdx.x;
+  if (i == 0) { *kept += (unsigned long long)(red[0] + 0.5); return; }
+  if (i <= n) { acc[gram_lin_pos(i - 1, n)] += red[i]; return; }
+  if (i < 1 + n + T) {
+    int q = i - 1 - n, j = 0;
+    if (kind) { acc[gram_quad_pos(q, q, n)] += red[i]; return; }
+    while (q >= n - j) { q -= n - j; j++; }
+    acc[gram_quad_pos(j, j + q, n)] += red[i];
+  }
+}
+
+// ---- sum_triple: key lists --------------------------------------------------------------------------
+// pass 0: every key of every lin_cat sub-list into its column's dictionary
+// pass 1: lin_cat values -> cnt, quad_num_cat values -> s, quad_cat values -> p (codes via the dictionaries)
+__global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayout L, CatDevice D, int pass) {
+  const int n = v.n, m = v.m;
+  const int Tm = v.kind ? 0 : tri_i(m), nm = v.kind ? 0 : n * m;
+  const uint64_t per_row = (uint64_t)m + (pass ? nm + Tm : 0);
+  const uint64_t total = v.count * per_row;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = w / per_row;
+    int s = (int)(w % per_row);
+    if (s < m) {
+      const int c = s;
+      const uint64_t sub = v.lc_outer[2 * i] + c, off = v.lc_sub[2 * sub], len = v.lc_sub[2 * sub + 1];
+      for (uint64_t e = off; e < off + len; e++) {
+        if (!pass) cat_dict_insert(D.ht_slot + L.ht_off[c], L.ht_cap[c], v.lc_key[e], D.flags);
+        else {
+          const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], v.lc_key[e]);
+          if (code < 0 || code >= L.kc[c]) { D.flags[1] = 1; continue; }
+          atomicAdd(&D.cnt[L.cnt_off[c] + code], (unsigned long long)(v.lc_val[e] + 0.5f));
+        }
+      }
+      continue;
+    }
+    s -= m;
+    if (s < nm) {
+      const int k = s / m, c = s % m;
+      const uint64_t sub = v.nc_outer[2 * i] + s, off = v.nc_sub[2 * sub], len = v.nc_sub[2 * sub + 1];
+      for (uint64_t e = off; e < off + len; e++) {
+        const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], v.nc_key[e]);
+        if (code < 0 || code >= L.kc[c]) { D.flags[1] = 1; continue; }
+        unsafeAtomicAdd(&D.s[L.s_off[c] + (long long)code * n + k], (double)v.nc_val[e]);
+      }
+      continue;
+    }
+    s -= nm;
+    {
+      int c1, c2;
+      pair_decode(s, m, c1, c2);
+      const uint64_t sub = v.cc_outer[2 * i] + s, off = v.cc_sub[2 * sub], len = v.cc_sub[2 * sub + 1];
+      for (uint64_t e = off; e < off + len; e++) {
+        const int k1 = cat_lookup_code(D.ht_slot + L.ht_off[c1], D.ht_code + L.ht_off[c1], L.ht_cap[c1], v.cc_key1[e]);
+        const int k2 = cat_lookup_code(D.ht_slot + L.ht_off[c2], D.ht_code + L.ht_off[c2], L.ht_cap[c2], v.cc_key2[e]);
+        if (k1 < 0 || k2 < 0 || k1 >= L.kc[c1] || k2 >= L.kc[c2]) { D.flags[1] = 1; continue; }
+        atomicAdd(&D.p[L.p_off[s] + (long long)k1 * L.kc[c2] + k2], (unsigned long long)(v.cc_val[e] + 0.5f));
+      }
+    }
+  }
+}
+
+// ---- multiply_triple -----------------------------------------------------------------------------
+struct MulShape { int nA, mA, nB, mB, kind; };
+
+// N, lin, quad of the product and their list entries: one thread per element (regular shape)
+__global__ __launch_bounds__(256) void mul_dense_kernel(cofactor_tvec a, const uint32_t *__restrict__ asel, cofactor_tvec b,
+                                                        const uint32_t *__restrict__ bsel, uint64_t rows, cofactor_tvec o) {
+  const int nA = a.n, nB = b.n, nR = nA + nB, kind = a.kind;
+  const int TR = kind ? nR : tri_i(nR);
+  const int D = 1 + nR + TR;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < rows * D; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = w / D;
+    const int e = (int)(w % D);
+    const uint64_t ia = asel ? asel[i] : i, ib = bsel ? bsel[i] : i;
+    const float Na = (float)a.N[ia], Nb = (float)b.N[ib];
+    const float *la = a.lin + a.lin_e[2 * ia], *lb = b.lin + b.lin_e[2 * ib];
+    const float *qa = a.quad + a.quad_e[2 * ia], *qb = b.quad + b.quad_e[2 * ib];
+    if (e == 0) {
+      o.N[i] = a.N[ia] * b.N[ib];                    // int32 product (mul.cpp:46-49)
+      o.lin_e[2 * i] = i * nR; o.lin_e[2 * i + 1] = nR;
+      o.quad_e[2 * i] = i * TR; o.quad_e[2 * i + 1] = TR;
+      // a list family without sub-lists (no key columns / no numeric columns): empty outer lists
+      const int mR = a.m + b.m;
+      if (mR == 0 && o.lc_outer) { o.lc_outer[2 * i] = 0; o.lc_outer[2 * i + 1] = 0; }
+      if (!kind && nR * mR == 0 && o.nc_outer) { o.nc_outer[2 * i] = 0; o.nc_outer[2 * i + 1] = 0; }
+      if (!kind && mR == 0 && o.cc_outer) { o.cc_outer[2 * i] = 0; o.cc_outer[2 * i + 1] = 0; }
+    } else if (e <= nR) {                            // lin = [N_B lin_A | N_A lin_B] (mul.cpp:97-107)
+      const int k = e - 1;
+      o.lin[i * nR + k] = k < nA ? la[k] * Nb : lb[k - nA] * Na;
+    } else {
+      int q = e - 1 - nR;
+      float val;
+      if (kind) val = q < nA ? qa[q] * Nb : qb[q - nA] * Na;          // mul_nb.cpp:246-262
+      else {                                         // upper triangle of [[N_B Q_A, lin_A (x) lin_B], [., N_A Q_B]]
+        int j = 0, r = q;
+        while (r >= nR - j) { r -= nR - j; j++; }
+        const int k = j + r;
+        if (k < nA) val = qa[pair_q(j, k, nA)] * Nb;
+        else if (j < nA) val = la[j] * lb[k - nA];
+        else val = qb[pair_q(j - nA, k - nA, nB)] * Na;
+      }
+      o.quad[i * TR + q] = val;
+    }
+  }
+}
+
+// Every output sub-list is one or two source sub-lists (mul.cpp:185-217, 377-446, 542-598):
+//   mode 0: its length -> len[] (then an exclusive scan gives the offsets)
+//   mode 1: entries, sub-list entry and (thread s == 0) the row's outer entry
+__global__ __launch_bounds__(256) void mul_lists_kernel(cofactor_tvec a, const uint32_t *__restrict__ asel, cofactor_tvec b,
+                                                        const uint32_t *__restrict__ bsel, uint64_t rows, int family,
+                                                        uint64_t *__restrict__ len, const uint64_t *__restrict__ offs,
+                                                        cofactor_tvec o, int mode) {
+  const int nA = a.n, mA = a.m, nB = b.n, mB = b.m, nR = nA + nB, mR = mA + mB;
+  const int per_row = family == 0 ? mR : (family == 1 ? nR * mR : tri_i(mR));
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < rows * per_row; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = w / per_row;
+    const int s = (int)(w % per_row);
+    const uint64_t ia = asel ? asel[i] : i, ib = bsel ? bsel[i] : i;
+    const float Na = (float)a.N[ia], Nb = (float)b.N[ib];
+    // source: up to two sub-lists (s1 x s2 = outer product when both are set), one scale factor
+    const uint64_t *e1 = nullptr, *e2 = nullptr;      // (offset, length) entries
+    const int32_t *k1 = nullptr, *k1b = nullptr, *k2 = nullptr;
+    const float *v1 = nullptr, *v2 = nullptr;
+    float scale = 1.f;
+    if (family == 0) {                               // lin_cat = [N_B lcat_A | N_A lcat_B]
+      if (s < mA) { e1 = a.lc_sub + 2 * (a.lc_outer[2 * ia] + s); k1 = a.lc_key; v1 = a.lc_val; scale = Nb; }
+      else { e1 = b.lc_sub + 2 * (b.lc_outer[2 * ib] + (s - mA)); k1 = b.lc_key; v1 = b.lc_val; scale = Na; }
+    } else if (family == 1) {                        // quad_num_cat, numeric-major over (A|B), key-minor over (A|B)
+      const int j = s / mR, c = s % mR;
+      if (j < nA && c < mA) { e1 = a.nc_sub + 2 * (a.nc_outer[2 * ia] + j * mA + c); k1 = a.nc_key; v1 = a.nc_val; scale = Nb; }
+      else if (j < nA) { e1 = b.lc_sub + 2 * (b.lc_outer[2 * ib] + (c - mA)); k1 = b.lc_key; v1 = b.lc_val; scale = a.lin[a.lin_e[2 * ia] + j]; }
+      else if (c < mA) { e1 = a.lc_sub + 2 * (a.lc_outer[2 * ia] + c); k1 = a.lc_key; v1 = a.lc_val; scale = b.lin[b.lin_e[2 * ib] + (j - nA)]; }
+      else { e1 = b.nc_sub + 2 * (b.nc_outer[2 * ib] + (j - nA) * mB + (c - mA)); k1 = b.nc_key; v1 = b.nc_val; scale = Na; }
+    } else {                                         // quad_cat over the joined key columns
+      int c1, c2;
+      pair_decode(s, mR, c1, c2);
+      if (c2 < mA) { e1 = a.cc_sub + 2 * (a.cc_outer[2 * ia] + pair_q(c1, c2, mA)); k1 = a.cc_key1; k1b = a.cc_key2; v1 = a.cc_val; scale = Nb; }
+      else if (c1 >= mA) { e1 = b.cc_sub + 2 * (b.cc_outer[2 * ib] + pair_q(c1 - mA, c2 - mA, mB)); k1 = b.cc_key1; k1b = b.cc_key2; v1 = b.cc_val; scale = Na; }
+      else {                                         // A x B: key-set outer product, count_A * count_B (mul.cpp:564-580)
+        e1 = a.lc_sub + 2 * (a.lc_outer[2 * ia] + c1); k1 = a.lc_key; v1 = a.lc_val;
+        e2 = b.lc_sub + 2 * (b.lc_outer[2 * ib] + (c2 - mA)); k2 = b.lc_key; v2 = b.lc_val;
+      }
+    }
+    const uint64_t l1 = e1[1], l2 = e2 ? e2[1] : 1;
+    if (mode == 0) { len[w] = l1 * l2; continue; }
+    const uint64_t off = offs[w];
+    uint64_t *sub = family == 0 ? o.lc_sub : (family == 1 ? o.nc_sub : o.cc_sub);
+    uint64_t *outer = family == 0 ? o.lc_outer : (family == 1 ? o.nc_outer : o.cc_outer);
+    sub[2 * w] = off; sub[2 * w + 1] = l1 * l2;
+    if (s == 0) { outer[2 * i] = w; outer[2 * i + 1] = (uint64_t)per_row; }
+    uint64_t t = off;
+    for (uint64_t x = 0; x < l1; x++) {
+      const uint64_t ea = e1[0] + x;
+      if (e2) {
+        for (uint64_t y = 0; y < l2; y++, t++) {
+          const uint64_t eb = e2[0] + y;
+          o.cc_key1[t] = k1[ea]; o.cc_key2[t] = k2[eb]; o.cc_val[t] = v1[ea] * v2[eb];
+        }
+      } else if (family == 2) {
+        o.cc_key1[t] = k1[ea]; o.cc_key2[t] = k1b[ea]; o.cc_val[t] = v1[ea] * scale; t++;
+      } else if (family == 1) {
+        o.nc_key[t] = k1[ea]; o.nc_val[t] = v1[ea] * scale; t++;
+      } else {
+        o.lc_key[t] = k1[ea]; o.lc_val[t] = v1[ea] * scale; t++;
+      }
+    }
+  }
+}
+
+// ---- GROUP BY state pool ---------------------------------------------------------------------------
+// Row g of tab (Dtot doubles): [N | lin(n) | quad(T) | cnt(n_cnt) | s(n_s) | p(n_p)], L's offsets.
+// A wave takes 64 consecutive rows: lane r stages row r (group, values, key codes) in LDS, then the
+// wave walks the rows and its lanes walk the row's cells, one double atomic each (a row's dense
+// cells are contiguous in its group's table row).
+constexpr int GR_THREADS = 256;
+
+__global__ __launch_bounds__(GR_THREADS) void groups_accumulate_kernel(const int32_t *__restrict__ gid, NumCols num,
+                                                                       CatCols cat, uint64_t rows, CatLayout L, CatDevice D,
+                                                                       CatLayout Lg, CatDevice Dg, int is_key,
+                                                                       double *__restrict__ tab, long long dtot) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int n = L.n, m = L.m, kind = L.kind;
+  const int T = kind ? n : tri_i(n), Dd = 1 + n + T;
+  const int ncat = m + (kind ? 0 : n * m + tri_i(m));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int stride = n + m + 1;                      // floats / ints per staged row
+  float *xs = reinterpret_cast<float *>(lds_raw) + (size_t)wave * 64 * stride;
+  int *is = reinterpret_cast<int *>(xs);
+  const uint64_t nchunks = (rows + 63) / 64;
+  for (uint64_t ch = (uint64_t)blockIdx.x * (GR_THREADS / 64) + wave; ch < nchunks; ch += (uint64_t)gridDim.x * (GR_THREADS / 64)) {
+    const uint64_t r = ch * 64 + lane;
+    const int valid = r < rows;
+    if (valid) {
+      int g = gid[r];
+      if (is_key) g = cat_lookup_code(Dg.ht_slot, Dg.ht_code, Lg.ht_cap[0], g);
+      is[lane * stride] = g;
+      for (int k = 0; k < n; k++) xs[lane * stride + 1 + k] = num.p[k][r];
+      for (int c = 0; c < m; c++)
+        is[lane * stride + 1 + n + c] = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], cat.p[c][r]);
+    }
+    const int nvalid = (int)min<uint64_t>(64, rows - ch * 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int rr = 0; rr < nvalid; rr++) {
+      const float *x = xs + rr * stride + 1;
+      const int *cd = is + rr * stride + 1 + n;
+      const int g = is[rr * stride];
+      if (g < 0) { if (lane == 0) D.flags[1] = 1; continue; }
+      double *row = tab + (long long)g * dtot;
+      for (int cell = lane; cell < Dd + ncat; cell += 64) {
+        long long idx = cell;
+        double val;
+        if (cell == 0) val = 1.0;
+        else if (cell <= n) val = (double)x[cell - 1];
+        else if (cell < Dd) {
+          int q = cell - 1 - n, j = 0, k;
+          if (kind) j = k = q;
+          else { while (q >= n - j) { q -= n - j; j++; } k = j + q; }
+          val = (double)(x[j] * x[k]);               // float product (sum_no_lift.cpp:139)
+        } else {
+          int u = cell - Dd;
+          if (u < m) {
+            if (cd[u] < 0) { D.flags[1] = 1; continue; }
+            idx = Dd + L.cnt_off[u] + cd[u]; val = 1.0;
+          } else if (u < m + n * m) {
+            u -= m;
+            const int c = u / n, k = u % n;
+            if (cd[c] < 0) continue;
+            idx = (long long)Dd + L.n_cnt + L.s_off[c] + (long long)cd[c] * n + k; val = (double)x[k];
+          } else {
+            int c1, c2;
+            pair_decode(u - m - n * m, m, c1, c2);
+            if (cd[c1] < 0 || cd[c2] < 0) continue;
+            idx = (long long)Dd + L.n_cnt + L.n_s + L.p_off[pair_q(c1, c2, m)] + (long long)cd[c1] * L.kc[c2] + cd[c2];
+            val = 1.0;
+          }
+        }
+        unsafeAtomicAdd(&row[idx], val);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// keys of a batch into the dictionaries: group keys (Lg / Dg, one column) and the key columns
+__global__ __launch_bounds__(256) void groups_insert_kernel(const int32_t *__restrict__ gid, CatCols cat, uint64_t rows,
+                                                            CatLayout L, CatDevice D, CatLayout Lg, CatDevice Dg, int is_key) {
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+    if (is_key) cat_dict_insert(Dg.ht_slot, Lg.ht_cap[0], gid[r], Dg.flags);
+    for (int c = 0; c < L.m; c++) cat_dict_insert(D.ht_slot + L.ht_off[c], L.ht_cap[c], cat.p[c][r], D.flags);
+  }
+}
+
+__global__ __launch_bounds__(256) void max_i32_kernel(const int32_t *__restrict__ v, uint64_t rows, int *__restrict__ out) {
+  int mx = -1;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) mx = max(mx, v[r]);
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, mx);
+}
+
+// table rows from one key-column layout to another (code capacities grew): cells keep their codes
+__global__ __launch_bounds__(256) void groups_relayout_kernel(CatLayout Lo, CatLayout Ln, const double *__restrict__ to,
+                                                              double *__restrict__ tn, long long dto, long long dtn, long long groups) {
+  const int n = Lo.n, m = Lo.m, kind = Lo.kind;
+  const int T = kind ? n : tri_i(n), Dd = 1 + n + T;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < groups * dto; w += (long long)gridDim.x * blockDim.x) {
+    const long long g = w / dto;
+    const int cell = (int)(w % dto);
+    long long idx;
+    if (cell < Dd) idx = cell;
+    else if (cell < Dd + Lo.n_cnt) {
+      const int u = cell - Dd;
+      int c = 0;
+      while (c + 1 < m && u >= Lo.cnt_off[c + 1]) c++;
+      idx = Dd + Ln.cnt_off[c] + (u - Lo.cnt_off[c]);
+    } else if (cell < Dd + Lo.n_cnt + Lo.n_s) {
+      const int u = cell - Dd - Lo.n_cnt;
+      int c = 0;
+      while (c + 1 < m && u >= Lo.s_off[c + 1]) c++;
+      idx = (long long)Dd + Ln.n_cnt + Ln.s_off[c] + (u - Lo.s_off[c]);
+    } else {
+      const int u = cell - Dd - Lo.n_cnt - Lo.n_s;
+      const int npairs = tri_i(m);
+      int q = 0;
+      while (q + 1 < npairs && u >= Lo.p_off[q + 1]) q++;
+      int c1, c2;
+      pair_decode(q, m, c1, c2);
+      const int local = u - Lo.p_off[q];
+      idx = (long long)Dd + Ln.n_cnt + Ln.n_s + Ln.p_off[q] + (long long)(local / Lo.kc[c2]) * Ln.kc[c2] + local % Lo.kc[c2];
+    }
+    tn[g * dtn + idx] = to[w];
+  }
+}
+
+__global__ __launch_bounds__(256) void groups_combine_kernel(double *__restrict__ tab, long long dtot, long long dst, long long src) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < dtot; i += (long long)gridDim.x * blockDim.x)
+    tab[dst * dtot + i] += tab[src * dtot + i];
+}
+
+// Groups -> a vector of triples (SumStateFinalize's layout, sum_state.cpp:116-464).  gorder[rank] = group
+// table row; ord[cnt_off[c] + r] = the code holding column c's r-th smallest key (-1 past the
+// last), keyof[cnt_off[c] + code] = its key.  mode 0: sub-list lengths; mode 1: fill.
+__global__ __launch_bounds__(256) void groups_lists_kernel(const double *__restrict__ tab, long long dtot, CatLayout L,
+                                                           const int32_t *__restrict__ gorder, long long groups,
+                                                           const int32_t *__restrict__ ord, const int32_t *__restrict__ keyof,
+                                                           int family, uint64_t *__restrict__ len,
+                                                           const uint64_t *__restrict__ offs, cofactor_tvec o, int mode) {
+  const int n = L.n, m = L.m, kind = L.kind;
+  const int T = kind ? n : tri_i(n), Dd = 1 + n + T;
+  const int per_row = family == 0 ? m : (family == 1 ? n * m : tri_i(m));
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < groups * per_row; w += (long long)gridDim.x * blockDim.x) {
+    const long long i = w / per_row;
+    const int s = (int)(w % per_row);
+    const double *row = tab + (long long)gorder[i] * dtot;
+    uint64_t cntv = 0;
+    const uint64_t off = mode ? offs[w] : 0;
+    if (family < 2) {
+      const int c = family == 0 ? s : s % m, k = family == 0 ? 0 : s / m;
+      const double *cnt = row + Dd + L.cnt_off[c];
+      const double *sum = row + Dd + L.n_cnt + L.s_off[c];
+      for (int r = 0; r < L.kc[c]; r++) {
+        const int code = ord[L.cnt_off[c] + r];
+        if (code < 0) break;
+        if (cnt[code] == 0.0) continue;              // key known to the dictionary, not to this group
+        if (mode) {
+          if (family == 0) { o.lc_key[off + cntv] = keyof[L.cnt_off[c] + code]; o.lc_val[off + cntv] = (float)cnt[code]; }
+          else { o.nc_key[off + cntv] = keyof[L.cnt_off[c] + code]; o.nc_val[off + cntv] = (float)sum[(long long)code * n + k]; }
+        }
+        cntv++;
+      }
+    } else {
+      int c1, c2;
+      pair_decode(s, m, c1, c2);
+      const double *p = row + Dd + L.n_cnt + L.n_s + L.p_off[s];
+      for (int r1 = 0; r1 < L.kc[c1]; r1++) {
+        const int k1 = ord[L.cnt_off[c1] + r1];
+        if (k1 < 0) break;
+        for (int r2 = 0; r2 < L.kc[c2]; r2++) {
+          const int k2 = ord[L.cnt_off[c2] + r2];
+          if (k2 < 0) break;
+          const double v = p[(long long)k1 * L.kc[c2] + k2];
+          if (v == 0.0) continue;
+          if (mode) {
+            o.cc_key1[off + cntv] = keyof[L.cnt_off[c1] + k1]; o.cc_key2[off + cntv] = keyof[L.cnt_off[c2] + k2];
+            o.cc_val[off + cntv] = (float)v;
+          }
+          cntv++;
+        }
+      }
+    }
+    if (!mode) { len[w] = cntv; continue; }
+    uint64_t *sub = family == 0 ? o.lc_sub : (family == 1 ? o.nc_sub : o.cc_sub);
+    uint64_t *outer = family == 0 ? o.lc_outer : (family == 1 ? o.nc_outer : o.cc_outer);
+    sub[2 * w] = off; sub[2 * w + 1] = cntv;
+    if (s == 0) { outer[2 * i] = (uint64_t)w; outer[2 * i + 1] = (uint64_t)per_row; }
+  }
+}
+
+__global__ __launch_bounds__(256) void groups_dense_kernel(const double *__restrict__ tab, long long dtot, int n, int T,
+                                                           const int32_t *__restrict__ gorder, long long groups, cofactor_tvec o) {
+  const int m = o.m, kind = o.kind;
+  const int D = 1 + n + T;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < groups * D; w += (long long)gridDim.x * blockDim.x) {
+    const long long i = w / D;
+    const int e = (int)(w % D);
+    const double v = tab[(long long)gorder[i] * dtot + e];
+    if (e == 0) {
+      o.N[i] = (int32_t)v;
+      o.lin_e[2 * i] = (uint64_t)i * n; o.lin_e[2 * i + 1] = n;
+      o.quad_e[2 * i] = (uint64_t)i * T; o.quad_e[2 * i + 1] = T;
+      if (m == 0 && o.lc_outer) { o.lc_outer[2 * i] = 0; o.lc_outer[2 * i + 1] = 0; }
+      if (!kind && n * m == 0 && o.nc_outer) { o.nc_outer[2 * i] = 0; o.nc_outer[2 * i + 1] = 0; }
+      if (!kind && m == 0 && o.cc_outer) { o.cc_outer[2 * i] = 0; o.cc_outer[2 * i + 1] = 0; }
+    } else if (e <= n) o.lin[i * n + (e - 1)] = (float)v;
+    else o.quad[i * T + (e - 1 - n)] = (float)v;
+  }
+}
+
+int grid_for(uint64_t items) {
+  const uint64_t b = (items + 255) / 256;
+  return (int)std::min<uint64_t>(std::max<uint64_t>(b, 1), 8192);
+}
+
+}  // namespace
+
+hipError_t launch_lift(const NumCols &num, const CatCols &cat, int n, int m, int kind, uint64_t rows,
+                       const cofactor_tvec &out, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  const int T = kind ? n : tri_i(n), Tm = kind ? 0 : tri_i(m), nm = kind ? 0 : n * m;
+  const uint64_t total = rows * (1 + (uint64_t)n + T + 5 + m + nm + Tm);
+  hipLaunchKernelGGL(lift_kernel, dim3(grid_for(total)), dim3(256), 0, stream, num, cat, n, m, kind, rows, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_tvec_dense(const cofactor_tvec &v, double *red, double *acc, unsigned long long *kept, int grid,
+                             hipStream_t stream) {
+  if (v.count == 0) return hipSuccess;
+  const int T = v.kind ? v.n : tri_i(v.n);
+  hipError_t e = hipMemsetAsync(red, 0, sizeof(double) * 256, stream);
+  if (e != hipSuccess) return e;
+  const uint64_t want = (v.count + 63) / 64;
+  hipLaunchKernelGGL(tvec_dense_kernel, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)grid)), dim3(256), 0, stream, v, T, red);
+  hipLaunchKernelGGL(tvec_dense_apply_kernel, dim3(1), dim3(256), 0, stream, red, v.n, v.kind, acc, kept);
+  return hipGetLastError();
+}
+
+hipError_t launch_tvec_keys(const cofactor_tvec &v, const CatLayout &L, const CatDevice &D, int pass, hipStream_t stream) {
+  if (v.count == 0 || v.m == 0) return hipSuccess;
+  const int Tm = v.kind ? 0 : tri_i(v.m), nm = v.kind ? 0 : v.n * v.m;
+  const uint64_t total = v.count * ((uint64_t)v.m + (pass ? nm + Tm : 0));
+  hipLaunchKernelGGL(tvec_keys_kernel, dim3(grid_for(total)), dim3(256), 0, stream, v, L, D, pass);
+  return hipGetLastError();
+}
+
+hipError_t launch_mul_dense(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
+                            uint64_t rows, const cofactor_tvec &out, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  const int nR = a.n + b.n, TR = a.kind ? nR : tri_i(nR);
+  hipLaunchKernelGGL(mul_dense_kernel, dim3(grid_for(rows * (1 + nR + TR))), dim3(256), 0, stream, a, asel, b, bsel, rows, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_mul_lists(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
+                            uint64_t rows, int family, uint64_t *len, const uint64_t *offs, const cofactor_tvec &out,
+                            int mode, hipStream_t stream) {
+  const int mR = a.m + b.m, nR = a.n + b.n;
+  const int per_row = family == 0 ? mR : (family == 1 ? nR * mR : tri_i(mR));
+  if (rows == 0 || per_row == 0) return hipSuccess;
+  hipLaunchKernelGGL(mul_lists_kernel, dim3(grid_for(rows * per_row)), dim3(256), 0, stream, a, asel, b, bsel, rows,
+                     family, len, offs, out, mode);
+  return hipGetLastError();
+}
+
+// exclusive prefix sums of len[0..items) into offs[0..items); *total (device) receives the grand total
+hipError_t ring_exclusive_scan(const uint64_t *len, uint64_t *offs, uint64_t items, void *temp, size_t *temp_bytes,
+                               hipStream_t stream) {
+  return hipcub::DeviceScan::ExclusiveSum(temp, *temp_bytes, len, offs, (int)items, stream);
+}
+
+hipError_t launch_groups_insert(const int32_t *gid, const CatCols &cat, uint64_t rows, const CatLayout &L,
+                                const CatDevice &D, const CatLayout &Lg, const CatDevice &Dg, int is_key, hipStream_t stream) {
+  if (rows == 0 || (!is_key && L.m == 0)) return hipSuccess;
+  hipLaunchKernelGGL(groups_insert_kernel, dim3(grid_for(rows)), dim3(256), 0, stream, gid, cat, rows, L, D, Lg, Dg, is_key);
+  return hipGetLastError();
+}
+
+hipError_t launch_max_i32(const int32_t *v, uint64_t rows, int *out, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(max_i32_kernel, dim3(grid_for(rows)), dim3(256), 0, stream, v, rows, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_groups_accumulate(const int32_t *gid, const NumCols &num, const CatCols &cat, uint64_t rows,
+                                    const CatLayout &L, const CatDevice &D, const CatLayout &Lg, const CatDevice &Dg,
+                                    int is_key, double *tab, long long dtot, int grid, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  const size_t lds = (size_t)(GR_THREADS / 64) * 64 * (L.n + L.m + 1) * 4;
+  const uint64_t want = (rows + GR_THREADS - 1) / GR_THREADS;
+  hipLaunchKernelGGL(groups_accumulate_kernel, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)grid)), dim3(GR_THREADS), lds,
+                     stream, gid, num, cat, rows, L, D, Lg, Dg, is_key, tab, dtot);
+  return hipGetLastError();
+}
+
+hipError_t launch_groups_relayout(const CatLayout &Lo, const CatLayout &Ln, const double *to, double *tn, long long dto,
+                                  long long dtn, long long groups, hipStream_t stream) {
+  if (groups == 0) return hipSuccess;
+  hipLaunchKernelGGL(groups_relayout_kernel, dim3(grid_for((uint64_t)(groups * dto))), dim3(256), 0, stream, Lo, Ln, to, tn, dto, dtn, groups);
+  return hipGetLastError();
+}
+
+hipError_t launch_groups_combine(double *tab, long long dtot, long long dst, long long src, hipStream_t stream) {
+  hipLaunchKernelGGL(groups_combine_kernel, dim3(grid_for((uint64_t)dtot)), dim3(256), 0, stream, tab, dtot, dst, src);
+  return hipGetLastError();
+}
+
+hipError_t launch_groups_lists(const double *tab, long long dtot, const CatLayout &L, const int32_t *gorder, long long groups,
+                               const int32_t *ord, const int32_t *keyof, int family, uint64_t *len, const uint64_t *offs,
+                               const cofactor_tvec &out, int mode, hipStream_t stream) {
+  const int per_row = family == 0 ? L.m : (family == 1 ? L.n * L.m : tri_i(L.m));
+  if (groups == 0 || per_row == 0) return hipSuccess;
+  hipLaunchKernelGGL(groups_lists_kernel, dim3(grid_for((uint64_t)(groups * per_row))), dim3(256), 0, stream, tab, dtot, L, gorder,
+                     groups, ord, keyof, family, len, offs, out, mode);
+  return hipGetLastError();
+}
+
+hipError_t launch_groups_dense(const double *tab, long long dtot, int n, int T, const int32_t *gorder, long long groups,
+                               const cofactor_tvec &out, hipStream_t stream) {
+  if (groups == 0) return hipSuccess;
+  hipLaunchKernelGGL(groups_dense_kernel, dim3(grid_for((uint64_t)(groups * (1 + n + T)))), dim3(256), 0, stream, tab, dtot, n, T,
+                     gorder, groups, out);
+  return hipGetLastError();
+}
+
+}  // namespace cofactor

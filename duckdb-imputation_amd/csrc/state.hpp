@@ -1,0 +1,116 @@
+// Internal: the objects behind the C ABI's opaque handles and the helpers the translation units of
+// the ABI layer (api.cpp, ring_api.cpp) share.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "device.hpp"
+#include "triple.hpp"
+
+struct cofactor_ctx {
+  // Aggregates of one context share its stream and scratch buffers (partials, pair slabs, skip
+  // list): every entry point that enqueues device work holds this lock for its whole sequence.
+  std::recursive_mutex mu;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int cus = 0;
+  int gram_grid = 0;            // workgroups of the Gram kernel
+  int cat_grid = 0;             // workgroups of the categorical kernel
+  size_t lds_budget = 0;        // bytes of LDS one categorical workgroup may claim
+  double *partials = nullptr;   // gram_grid * GRAM_ACC_LEN doubles
+  unsigned *pair_slabs = nullptr;   // fused kernel: one u32 pair table per workgroup
+  size_t pair_slab_bytes = 0;
+  // optional HIP-event timing of the two streaming kernels (cofactor_ctx_profile_*)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev, fused_ev;
+  bool allow_fused = true;      // COFACTOR_NO_FUSED=1 forces the two-kernel path
+  int fused_pref = 0;           // COFACTOR_FUSED=1 / 2: only fused_kernel / only fused2_kernel (A/B runs);
+                                // default: fused_kernel where it applies (faster at 10_10), else fused2_kernel
+  bool allow_optimistic = true; // COFACTOR_NO_OPTIMISTIC=1: always run the dictionary pass first
+  unsigned *skip = nullptr;     // optimistic fused pass: [count, tile ids...]
+  size_t skip_bytes = 0;
+  size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
+  double *ring_red = nullptr;   // 256 doubles: reduced dense children of a vector of triples (sum_triple)
+};
+
+#define CTX_LOCK(ctxp) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxp)->mu)
+
+struct cofactor_agg {
+  cofactor_ctx *ctx = nullptr;
+  int n = 0, m = 0, kind = 0;
+  cofactor::HostTriple host;    // everything merged in on the host (combine, lifted triples, import)
+  double dev_rows = 0;          // rows (of unmasked updates) whose contributions sit in the device tables
+  unsigned long long *d_kept = nullptr;   // device counter: rows kept by masked updates
+  bool dev_dirty = false;       // the device tables hold something
+  double *d_acc = nullptr;      // dense accumulator image (GRAM_ACC_LEN doubles)
+  // categorical device state
+  bool cat_ready = false;
+  bool cat_check_pending = false;
+  int32_t nkeys_host[COFACTOR_MAX_CAT] = {0};
+  // finalize's two-call protocol: the blob of the size query is kept for the fill call
+  std::vector<double> blob_cache;
+  bool blob_cache_valid = false;
+  cofactor::CatLayout L{};
+  cofactor::CatDevice D{};
+  // host staging for update_host (pinned) and its device mirror, both double-buffered: while
+  // buffer b is on its way to the device (copy + kernels, asynchronous), chunks land in b ^ 1
+  uint64_t stage_cap = 0, stage_rows = 0;
+  int stage_buf = 0;
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
+  float *h_num = nullptr;
+  int32_t *h_cat = nullptr;
+  float *d_num = nullptr;
+  int32_t *d_cat = nullptr;
+  // dense seam: the host-side dense addends on their way to the export kernel
+  double *d_host_dense = nullptr;
+  std::vector<double> host_dense_stage;
+  // table seam: signature of the key lists the dictionaries were last aligned to (0 = the
+  // dictionaries have changed since, or were never aligned)
+  uint64_t dict_sig = 0;
+};
+
+namespace cofactor {
+namespace detail {
+
+cofactor_status fail(cofactor_status st, const std::string &msg);
+cofactor_status hip_fail(hipError_t e, const char *what);
+long env_long(const char *name, long dflt);
+int next_pow2(int v);
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// categorical state management shared with the ring ops (api.cpp)
+void cat_free(CatDevice &D);
+bool cat_finish_layout(CatLayout &L);
+cofactor_status cat_alloc(const CatLayout &L, CatDevice &D, bool fresh_counters, hipStream_t st);
+cofactor_status cat_regrow(cofactor_agg *a, const CatLayout &Lnew);
+cofactor_status cat_prepare(cofactor_agg *a);
+cofactor_status stage_flush(cofactor_agg *a);
+// dictionary maintenance for one batch of keys: `insert` launches the kernel that puts the batch's
+// keys into a->D (geometry a->L); unseen keys get codes, dictionaries and tables grow as needed
+cofactor_status cat_dictionaries_with(cofactor_agg *a, const std::function<hipError_t()> &insert);
+cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t rows);
+cofactor_status emit_blob(const std::vector<double> &blob, double *out, uint64_t cap, uint64_t *needed);
+
+}  // namespace detail
+}  // namespace cofactor
+
+#define HIP_TRY(expr)                                                  \
+  do {                                                                 \
+    hipError_t e_ = (expr);                                            \
+    if (e_ != hipSuccess) return cofactor::detail::hip_fail(e_, #expr); \
+  } while (0)

@@ -226,6 +226,111 @@ cofactor_status cofactor_triple_sub(const double *a, uint64_t a_len, const doubl
  * every list header against it before reading. */
 uint64_t cofactor_blob_len(const double *blob, uint64_t cap);
 
+/* ---- batched ring ops on the GPU (the factorised-join pipeline) ----------------
+ *
+ *   SELECT sum_triple(multiply_triple(A, B)) FROM
+ *     (SELECT gb, sum_to_triple_2_2(b,c,d,e) AS A FROM test1 GROUP BY gb) a  JOIN
+ *     (SELECT gb, sum_to_triple_2_2(a,c,d,f) AS B FROM test2 GROUP BY gb) b  ON a.gb = b.gb
+ *                                                               (the reference's README.md:163-173)
+ *
+ * cofactor_tvec — a VECTOR of triples in device (or host) memory, laid out exactly as the
+ * reference's result STRUCT vector is laid out by DuckDB after RecursiveFlatten
+ * (sum_state.cpp:116-464, lift.cpp:225-241): one array per leaf field, list_entry_t =
+ * {uint64 offset, uint64 length} pairs for every list level.  Row i of the vector:
+ *   N[i];  lin[lin_e[i]];  quad[quad_e[i]]                       (FLOAT children of two LISTs)
+ *   lin_cat:      outer entry lc_outer[i] -> m sub-lists lc_sub[..] -> entries (lc_key, lc_val)
+ *   quad_num_cat: outer entry nc_outer[i] -> n*m sub-lists (index k*m + c) -> (nc_key, nc_val)
+ *   quad_cat:     outer entry cc_outer[i] -> m(m+1)/2 sub-lists -> (cc_key1, cc_key2, cc_val)
+ * Every row has the same n and m (as the reference assumes, sum.cpp:99-106, mul.cpp:57-69).
+ * For kind = COFACTOR_NB quad holds the n diagonal entries and the nc / cc members are unused.
+ * `list_entry` arrays are pairs of uint64 (offset, length), i.e. a duckdb::list_entry_t array can
+ * be passed as is. */
+typedef struct {
+  uint64_t count;                 /* rows (triples) */
+  int32_t n, m, kind;
+  int32_t *N;                     /* [count] */
+  uint64_t *lin_e;  float *lin;   /* [count] entries; lin child [count * n] */
+  uint64_t *quad_e; float *quad;  /* [count] entries; quad child */
+  uint64_t *lc_outer, *lc_sub; int32_t *lc_key; float *lc_val;
+  uint64_t *nc_outer, *nc_sub; int32_t *nc_key; float *nc_val;
+  uint64_t *cc_outer, *cc_sub; int32_t *cc_key1, *cc_key2; float *cc_val;
+  /* entries of the payload arrays: capacity for the ops that write them, extent for inputs */
+  uint64_t lc_cap, nc_cap, cc_cap;
+  /* extents of the other arrays (only the *_host entry points, which copy them, look at these):
+   * floats in lin / quad, (offset, length) pairs in lc_sub / nc_sub / cc_sub */
+  uint64_t lin_len, quad_len, lc_subs, nc_subs, cc_subs;
+} cofactor_tvec;
+
+/* to_cofactor / to_nb_agg on the GPU — Triple::CustomLift (triple/lift.cpp:15-243), to_nb_lift
+ * (triple/lift_to_nb_agg.cpp:13-136): one triple per row of the device columns, written into the
+ * caller's device arrays `out` (regular shape: every sub-list has exactly one entry, so
+ * lc_cap >= rows*m, nc_cap >= rows*n*m, cc_cap >= rows*m(m+1)/2; lin [rows*n], quad
+ * [rows*n(n+1)/2 | rows*n]).  An expand kernel, HBM-write bound:
+ *   4 (1 + n + T) + 32 + 16 (3 + m + n m + T_m) + 8 (m + n m) + 12 T_m   bytes written per row
+ * against 4 (n + m) read  (T = n(n+1)/2 or n, T_m = m(m+1)/2; 0 for the nc / cc parts of NB). */
+cofactor_status cofactor_lift_device(cofactor_ctx *ctx, const float *const *d_num, int n_num,
+                                     const int32_t *const *d_cat, int n_cat, uint64_t rows,
+                                     cofactor_kind kind, cofactor_tvec *out);
+
+/* sum_triple / sum_nb_agg on the GPU — Triple::Sum (triple/sum/sum.cpp:57-261), sum_nb_agg
+ * (sum_nb_agg.cpp:45-175): adds every row of the device vector `v` to the state.  The dense
+ * children are reduced column-wise by a streaming kernel (4 (1 + n + T) bytes read per row); the
+ * key lists go through the state's dictionaries into its count / sum / pair tables. */
+cofactor_status cofactor_agg_update_tvec_device(cofactor_agg *agg, const cofactor_tvec *v);
+
+/* multiply_triple / multiply_nb_agg on the GPU — Triple::MultiplyFunction (triple/mul.cpp:19-611),
+ * multiply_nb (mul_nb.cpp:20-268): out row i = a row (a_sel ? a_sel[i] : i)  x  b row
+ * (b_sel ? b_sel[i] : i), i < rows (the selection vectors are what a join hands the function).
+ * Two-call protocol on the payload sizes: with out == NULL (or capacities too small ->
+ * COFACTOR_ERR_CAPACITY) only *lc_need / *nc_need / *cc_need are set (entries of the three payload
+ * arrays).  N is the int32 product, as in the reference (mul.cpp:46-49). */
+cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec *a,
+                                         const uint32_t *d_a_sel, const cofactor_tvec *b,
+                                         const uint32_t *d_b_sel, uint64_t rows, cofactor_tvec *out,
+                                         uint64_t *lc_need, uint64_t *nc_need, uint64_t *cc_need);
+
+/* The same three over HOST arrays (a DuckDB DataChunk / result vector): staged to the device,
+ * computed there, copied back.  `out` arrays are host memory sized by the caller (lift: regular
+ * shape, see above; multiply: two-call protocol). */
+cofactor_status cofactor_lift_host_tvec(cofactor_ctx *ctx, const float *const *num, int n_num,
+                                        const int32_t *const *cat, int n_cat, uint64_t rows,
+                                        cofactor_kind kind, cofactor_tvec *out);
+cofactor_status cofactor_agg_update_tvec_host(cofactor_agg *agg, const cofactor_tvec *v);
+cofactor_status cofactor_multiply_host(cofactor_ctx *ctx, const cofactor_tvec *a, const uint32_t *a_sel,
+                                       const cofactor_tvec *b, const uint32_t *b_sel, uint64_t rows,
+                                       cofactor_tvec *out, uint64_t *lc_need, uint64_t *nc_need,
+                                       uint64_t *cc_need);
+
+/* GROUP BY: all groups of one aggregate in ONE device state pool, one kernel launch per batch
+ * whatever the number of groups — the per-row state pointers of Triple::SumNoLift
+ * (sum_no_lift.cpp:84,94,139,161,201) as a per-row group id.  Group g owns row g of a dense
+ * table [ N | lin | quad | key counts | per-key sums | pair counts ] (dictionary-coded keys), so a
+ * join key with 1e5 values costs 1e5 table rows, not 1e5 states with their own buffers.
+ *   gid: group of every row — slot ids 0..G-1 handed out by the caller (is_key = 0; the DuckDB
+ *        glue numbers its SumStates), or arbitrary int32 keys (is_key = 1; GROUP BY column).
+ * combine: Triple::SumStateCombine per group (dst += src; src unchanged).
+ * finalize: one group's triple as a flat blob (two-call protocol), keys ascending.
+ * to_tvec: every group's triple, in ascending group order (is_key = 1: ascending key; the keys go to
+ *          d_group_keys if not NULL), as one device vector — the input of cofactor_multiply_device.
+ *          Two-call protocol like cofactor_multiply_device. */
+typedef struct cofactor_groups cofactor_groups;
+cofactor_status cofactor_groups_create(cofactor_ctx *ctx, int n_num, int n_cat, cofactor_kind kind,
+                                       int is_key, cofactor_groups **out);
+void cofactor_groups_destroy(cofactor_groups *grp);
+cofactor_status cofactor_groups_update_device(cofactor_groups *grp, const int32_t *d_gid,
+                                              const float *const *d_num,
+                                              const int32_t *const *d_cat, uint64_t rows);
+cofactor_status cofactor_groups_update_host(cofactor_groups *grp, const int32_t *gid,
+                                            const float *const *num, const int32_t *const *cat,
+                                            uint64_t rows);
+cofactor_status cofactor_groups_count(cofactor_groups *grp, uint64_t *n_groups);
+cofactor_status cofactor_groups_combine(cofactor_groups *grp, int32_t dst_gid, int32_t src_gid);
+cofactor_status cofactor_groups_finalize(cofactor_groups *grp, int32_t gid, double *out,
+                                         uint64_t cap, uint64_t *needed);
+cofactor_status cofactor_groups_to_tvec(cofactor_groups *grp, cofactor_tvec *out,
+                                        int32_t *d_group_keys, uint64_t *lc_need,
+                                        uint64_t *nc_need, uint64_t *cc_need);
+
 /* ---- consumers of the triple (what one MICE iteration needs) --------------
  * Training is host fp64 over the p x p cofactor matrix (p = 1 + n + #keys, independent of the
  * row count) and emits the reference's flat FLOAT[] parameter vector; prediction is a HIP kernel
