@@ -3,11 +3,13 @@
 // (reference: duckdb_extension/src/duckdb_imputation_extension.cpp:48-180) and forwards every
 // callback across the C ABI of include/cofactor_hip.h.
 //
-//   sum_to_triple_<x>_<y>(FLOAT*x, INTEGER*y)   x,y in 0..20      -> update_host / combine / finalize
+//   sum_to_triple_<x>_<y>(FLOAT*x, INTEGER*y)   x,y in 0..20      -> update_host / combine / finalize; with GROUP BY
+//                                                                     one cofactor_groups pool per query, one
+//                                                                     cofactor_groups_update_host per chunk
 //   sum_to_nb_agg_<x>_<y>(...)                                     -> same, kind = NB
-//   sum_triple(triple), sum_nb_agg(triple)                          -> update_triples
-//   to_cofactor(cols...), to_nb_agg(cols...)                        -> cofactor_lift_host
-//   multiply_triple(a, b), multiply_nb_agg(a, b)                    -> cofactor_triple_multiply
+//   sum_triple(triple), sum_nb_agg(triple)                          -> cofactor_agg_update_tvec_host (child arrays as is)
+//   to_cofactor(cols...), to_nb_agg(cols...)                        -> cofactor_lift_host_tvec (writes the result's child arrays)
+//   multiply_triple(a, b), multiply_nb_agg(a, b)                    -> cofactor_multiply_host (child arrays in, child arrays out)
 //   linreg_train(triple, label, step, lambda, iters, variance, normalize)  -> cofactor_linreg_train
 //   lda_train(triple, label, shrinkage, normalize)                  -> cofactor_lda_train
 //   linreg_predict(params, noise, normalize, cols...)               -> cofactor_linreg_predict_host
@@ -22,6 +24,8 @@
 #include "duckdb_imputation_extension.hpp"
 
 #include <atomic>
+#include <cstring>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <unordered_map>
@@ -54,16 +58,34 @@ static void Check(cofactor_status st) {
 
 // ---- aggregate state: a POD handle, memcpy-relocatable like Triple::SumState ---------------------
 // (reference: duckdb_extension/src/include/triple/sum/sum_state.h:14-57)
+// A state fed by chunks that are all its own (no GROUP BY, or a group that fills whole chunks) owns
+// a cofactor_agg; a state first met in a chunk with several states is a slot of the query's GROUP BY
+// pool (one device table row per group, one kernel launch per chunk).  A state may hold both.
+struct GroupPool {
+  std::mutex mu;
+  cofactor_groups *grp = nullptr;
+  int32_t next_slot = 0;
+  ~GroupPool() { cofactor_groups_destroy(grp); }
+};
+
 struct RingState {
   cofactor_agg *agg;
+  GroupPool *pool;
+  int32_t slot;
+};
+
+// bind data of the aggregates: the return type (as the reference's VariableReturnBindData) + the pool
+struct RingBindData : public VariableReturnBindData {
+  explicit RingBindData(LogicalType t) : VariableReturnBindData(std::move(t)), pool(std::make_shared<GroupPool>()) {}
+  std::shared_ptr<GroupPool> pool;
 };
 
 struct RingStateFunction {
   template <class STATE>
-  static void Initialize(STATE &state) { state.agg = nullptr; }
+  static void Initialize(STATE &state) { state.agg = nullptr; state.pool = nullptr; state.slot = -1; }
   template <class STATE>
   static void Destroy(STATE &state, AggregateInputData &) {
-    cofactor_agg_destroy(state.agg);
+    cofactor_agg_destroy(state.agg);                  // (a slot lives and dies with the query's pool)
     state.agg = nullptr;
   }
   static bool IgnoreNull() { return false; }
@@ -222,7 +244,7 @@ static void RowToBlob(Vector &triple, idx_t row, bool nb, std::vector<double> &b
 // ---- aggregate callbacks --------------------------------------------------------------------------
 // update: Triple::SumNoLift / Triple::sum_to_nb_agg (sum_no_lift.cpp:53-216, sum_to_nb_agg.cpp:39-146)
 template <bool NB>
-static void RingUpdate(Vector inputs[], AggregateInputData &, idx_t cols, Vector &state_vector, idx_t count) {
+static void RingUpdate(Vector inputs[], AggregateInputData &aggr, idx_t cols, Vector &state_vector, idx_t count) {
   UnifiedVectorFormat sdata;
   state_vector.ToUnifiedFormat(count, sdata);
   auto states = (RingState **)sdata.data;
@@ -237,19 +259,112 @@ static void RingUpdate(Vector inputs[], AggregateInputData &, idx_t cols, Vector
     if (IsNumeric(inputs[j].GetType())) { num.push_back((const float *)fmt[j].data); num_sel.push_back(sel); }
     else { cat.push_back((const int32_t *)fmt[j].data); cat_sel.push_back(sel); }
   }
-  // rows of this chunk per distinct state (GROUP BY); one state in the ungrouped case
-  std::unordered_map<RingState *, vector<uint32_t>> rows_of;
   RingState *first = states[sdata.sel->get_index(0)];
   bool single = true;
   for (idx_t i = 1; i < count && single; i++) single = states[sdata.sel->get_index(i)] == first;
+  const cofactor_kind kind = NB ? COFACTOR_NB : COFACTOR_TRIPLE;
   auto feed = [&](RingState *st, const uint32_t *row_idx, idx_t rows) {
-    if (!st->agg)
-      Check(cofactor_agg_create(Context(), (int)num.size(), (int)cat.size(), NB ? COFACTOR_NB : COFACTOR_TRIPLE, &st->agg));
+    if (!st->agg) Check(cofactor_agg_create(Context(), (int)num.size(), (int)cat.size(), kind, &st->agg));
     Check(cofactor_agg_update_host(st->agg, num.data(), cat.data(), num_sel.data(), cat_sel.data(), row_idx, rows));
   };
-  if (single) { feed(first, nullptr, count); return; }
-  for (idx_t i = 0; i < count; i++) rows_of[states[sdata.sel->get_index(i)]].push_back((uint32_t)i);
+  if (single && first->slot < 0) { feed(first, nullptr, count); return; }
+  // GROUP BY: the rows of states that own an aggregate go to it; all others are slots of the pool
+  // and go to the device in ONE call with their slot as the per-row group id
+  // (the per-row state pointers of sum_no_lift.cpp:84,94,139)
+  GroupPool *pool = aggr.bind_data->template Cast<RingBindData>().pool.get();
+  std::unordered_map<RingState *, vector<uint32_t>> rows_of;
+  vector<int32_t> gid;
+  vector<uint32_t> pooled;
+  {
+    std::lock_guard<std::mutex> lock(pool->mu);
+    if (!pool->grp) Check(cofactor_groups_create(Context(), (int)num.size(), (int)cat.size(), kind, /*is_key=*/0, &pool->grp));
+    for (idx_t i = 0; i < count; i++) {
+      RingState *st = states[sdata.sel->get_index(i)];
+      if (st->agg && st->slot < 0) { rows_of[st].push_back((uint32_t)i); continue; }
+      if (st->slot < 0) { st->slot = pool->next_slot++; st->pool = pool; }
+      if (st->pool != pool) throw InvalidInputException("duckdb_imputation: aggregate state used with a foreign group pool");
+      gid.push_back(st->slot);
+      pooled.push_back((uint32_t)i);
+    }
+  }
   for (auto &kv : rows_of) feed(kv.first, kv.second.data(), kv.second.size());
+  if (pooled.empty()) return;
+  vector<vector<float>> gnum(num.size(), vector<float>(pooled.size()));
+  vector<vector<int32_t>> gcat(cat.size(), vector<int32_t>(pooled.size()));
+  vector<const float *> pn;
+  vector<const int32_t *> pc;
+  for (size_t k = 0; k < num.size(); k++) {
+    for (size_t i = 0; i < pooled.size(); i++) gnum[k][i] = num[k][num_sel[k] ? num_sel[k][pooled[i]] : pooled[i]];
+    pn.push_back(gnum[k].data());
+  }
+  for (size_t c = 0; c < cat.size(); c++) {
+    for (size_t i = 0; i < pooled.size(); i++) gcat[c][i] = cat[c][cat_sel[c] ? cat_sel[c][pooled[i]] : pooled[i]];
+    pc.push_back(gcat[c].data());
+  }
+  std::lock_guard<std::mutex> lock(pool->mu);
+  Check(cofactor_groups_update_host(pool->grp, gid.data(), pn.data(), pc.data(), pooled.size()));
+}
+
+// A (recursively flattened) triple STRUCT vector as a cofactor_tvec: pointers to its child arrays,
+// nothing is copied (list_entry_t = {uint64 offset, uint64 length}).  Rows must share n and m
+// and carry list counts that fit them, as the reference assumes (sum.cpp:99-106, mul.cpp:57-69).
+static void VectorAsTvec(Vector &triple, idx_t count, bool nb, cofactor_tvec &tv) {
+  auto &children = StructVector::GetEntries(triple);
+  auto entries = [](Vector &list) { return reinterpret_cast<uint64_t *>(FlatVector::GetData<list_entry_t>(list)); };
+  std::memset(&tv, 0, sizeof(tv));
+  tv.count = count;
+  tv.kind = nb ? COFACTOR_NB : COFACTOR_TRIPLE;
+  tv.N = FlatVector::GetData<int32_t>(*children[0]);
+  tv.lin_e = entries(*children[1]);
+  tv.lin = FlatVector::GetData<float>(ListVector::GetEntry(*children[1]));
+  tv.lin_len = ListVector::GetListSize(*children[1]);
+  tv.quad_e = entries(*children[2]);
+  tv.quad = FlatVector::GetData<float>(ListVector::GetEntry(*children[2]));
+  tv.quad_len = ListVector::GetListSize(*children[2]);
+  auto lists = [&](Vector &outer, bool two_keys, uint64_t *&o_e, uint64_t *&s_e, int32_t *&k1, int32_t *&k2, float *&val,
+                   uint64_t &subs, uint64_t &payload) {
+    o_e = entries(outer);
+    Vector &mid = ListVector::GetEntry(outer);
+    s_e = entries(mid);
+    subs = ListVector::GetListSize(outer);
+    payload = ListVector::GetListSize(mid);
+    auto &fields = StructVector::GetEntries(ListVector::GetEntry(mid));
+    k1 = FlatVector::GetData<int32_t>(*fields[0]);
+    if (two_keys) k2 = FlatVector::GetData<int32_t>(*fields[1]);
+    val = FlatVector::GetData<float>(*fields[two_keys ? 2 : 1]);
+  };
+  int32_t *unused = nullptr;
+  lists(*children[3], false, tv.lc_outer, tv.lc_sub, tv.lc_key, unused, tv.lc_val, tv.lc_subs, tv.lc_cap);
+  if (!nb) {
+    lists(*children[4], false, tv.nc_outer, tv.nc_sub, tv.nc_key, unused, tv.nc_val, tv.nc_subs, tv.nc_cap);
+    lists(*children[5], true, tv.cc_outer, tv.cc_sub, tv.cc_key1, tv.cc_key2, tv.cc_val, tv.cc_subs, tv.cc_cap);
+  }
+  if (count == 0) return;
+  const uint64_t n = tv.lin_e[1], m = tv.lc_outer[1];
+  tv.n = (int32_t)n; tv.m = (int32_t)m;
+  for (idx_t i = 0; i < count; i++) {
+    bool ok = tv.lin_e[2 * i + 1] == n && tv.lc_outer[2 * i + 1] == m && tv.quad_e[2 * i + 1] == (nb ? n : n * (n + 1) / 2);
+    if (!nb) ok = ok && tv.nc_outer[2 * i + 1] == n * m && tv.cc_outer[2 * i + 1] == m * (m + 1) / 2;
+    if (!ok) throw InvalidInputException("triple argument: list lengths do not match its lin_agg / lin_cat lengths");
+  }
+}
+
+// The result STRUCT vector sized for `rows` triples of shape (n, m) whose payload lists hold
+// lc / nc / cc entries, as a cofactor_tvec the kernels' results are copied into.
+static void ResultAsTvec(Vector &result, idx_t rows, idx_t n, idx_t m, bool nb, idx_t lc, idx_t nc, idx_t cc, cofactor_tvec &tv) {
+  auto &children = StructVector::GetEntries(result);
+  const idx_t T = nb ? n : n * (n + 1) / 2;
+  ReserveList(*children[1], rows * n);
+  ReserveList(*children[2], rows * T);
+  auto size_lists = [&](Vector &outer, idx_t subs, idx_t payload) {
+    ReserveList(outer, subs);
+    ReserveList(ListVector::GetEntry(outer), payload);
+  };
+  size_lists(*children[3], rows * m, lc);
+  if (!nb) { size_lists(*children[4], rows * n * m, nc); size_lists(*children[5], rows * m * (m + 1) / 2, cc); }
+  VectorAsTvec(result, 0, nb, tv);                    // pointers only (fetched after the Reserves)
+  tv.count = rows; tv.n = (int32_t)n; tv.m = (int32_t)m;
+  tv.lc_cap = lc; tv.nc_cap = nc; tv.cc_cap = cc;
 }
 
 // update of sum_triple / sum_nb_agg: Triple::Sum (sum.cpp:57-261), sum_nb_agg (sum_nb_agg.cpp:45-175)
@@ -260,7 +375,17 @@ static void RingUpdateTriples(Vector inputs[], AggregateInputData &, idx_t input
   state_vector.ToUnifiedFormat(count, sdata);
   auto states = (RingState **)sdata.data;
   RecursiveFlatten(inputs[0], count);
-  std::vector<double> blob;
+  RingState *first = states[sdata.sel->get_index(0)];
+  bool single = true;
+  for (idx_t i = 1; i < count && single; i++) single = states[sdata.sel->get_index(i)] == first;
+  if (single) {                                       // the whole chunk into one state: one device call
+    cofactor_tvec tv;
+    VectorAsTvec(inputs[0], count, NB, tv);
+    if (!first->agg) Check(cofactor_agg_create(Context(), tv.n, tv.m, NB ? COFACTOR_NB : COFACTOR_TRIPLE, &first->agg));
+    Check(cofactor_agg_update_tvec_host(first->agg, &tv));
+    return;
+  }
+  std::vector<double> blob;                           // GROUP BY over triples: row by row
   for (idx_t i = 0; i < count; i++) {
     blob.clear();
     RowToBlob(inputs[0], i, NB, blob);
@@ -273,16 +398,54 @@ static void RingUpdateTriples(Vector inputs[], AggregateInputData &, idx_t input
 }
 
 // combine: Triple::SumStateCombine (sum_state.cpp:10-114)
+// one group's triple as a flat blob: what its aggregate and / or its pool slot hold
+static bool StateBlob(RingState *st, std::vector<double> &blob) {
+  std::vector<double> a, b;
+  uint64_t need = 0;
+  if (st->agg) {
+    Check(cofactor_agg_finalize(st->agg, nullptr, 0, &need));
+    a.resize(need);
+    Check(cofactor_agg_finalize(st->agg, a.data(), need, &need));
+  }
+  if (st->slot >= 0) {
+    std::lock_guard<std::mutex> lock(st->pool->mu);
+    Check(cofactor_groups_finalize(st->pool->grp, st->slot, nullptr, 0, &need));
+    b.resize(need);
+    Check(cofactor_groups_finalize(st->pool->grp, st->slot, b.data(), need, &need));
+  }
+  if (a.empty() && b.empty()) return false;
+  if (a.empty() || b.empty()) { blob = a.empty() ? std::move(b) : std::move(a); return true; }
+  Check(cofactor_triple_add(a.data(), a.size(), b.data(), b.size(), nullptr, 0, &need));
+  blob.resize(need);
+  Check(cofactor_triple_add(a.data(), a.size(), b.data(), b.size(), blob.data(), need, &need));
+  return true;
+}
+
 static void RingCombine(Vector &state, Vector &combined, AggregateInputData &, idx_t count) {
   UnifiedVectorFormat sdata;
   state.ToUnifiedFormat(count, sdata);
   auto src = (RingState **)sdata.data;
   auto dst = FlatVector::GetData<RingState *>(combined);
   for (idx_t i = 0; i < count; i++) {
-    RingState *s = src[sdata.sel->get_index(i)];
-    if (!s->agg) continue;                            // empty thread-local state
-    if (!dst[i]->agg) { dst[i]->agg = s->agg; s->agg = nullptr; continue; }   // adopt
-    Check(cofactor_agg_combine(dst[i]->agg, s->agg));
+    RingState *s = src[sdata.sel->get_index(i)], *d = dst[i];
+    if (s->slot >= 0) {                               // pool slots: one row add on the device
+      if (d->slot < 0) { d->slot = s->slot; d->pool = s->pool; s->slot = -1; }
+      else if (d->pool == s->pool) {
+        std::lock_guard<std::mutex> lock(d->pool->mu);
+        Check(cofactor_groups_combine(d->pool->grp, d->slot, s->slot));
+      } else {                                        // slots of different pools: through the blob
+        std::vector<double> blob;
+        RingState only_slot = {nullptr, s->pool, s->slot};
+        if (StateBlob(&only_slot, blob)) {
+          if (!d->agg) Check(cofactor_agg_create(Context(), (int)blob[1], (int)blob[2], blob[0] != 0 ? COFACTOR_NB : COFACTOR_TRIPLE, &d->agg));
+          const uint64_t offs[2] = {0, blob.size()};
+          Check(cofactor_agg_update_triples(d->agg, blob.data(), offs, 1));
+        }
+      }
+    }
+    if (!s->agg) continue;                            // nothing (more) in the thread-local state
+    if (!d->agg) { d->agg = s->agg; s->agg = nullptr; continue; }   // adopt
+    Check(cofactor_agg_combine(d->agg, s->agg));
   }
 }
 
@@ -296,11 +459,7 @@ static void RingFinalize(Vector &state_vector, AggregateInputData &, Vector &res
   std::vector<double> blob;
   for (idx_t i = 0; i < count; i++) {
     RingState *st = states[sdata.sel->get_index(i)];
-    if (!st->agg) { FlatVector::SetNull(result, i + offset, true); continue; }
-    uint64_t need = 0;
-    Check(cofactor_agg_finalize(st->agg, nullptr, 0, &need));
-    blob.resize(need);
-    Check(cofactor_agg_finalize(st->agg, blob.data(), need, &need));
+    if (!StateBlob(st, blob)) { FlatVector::SetNull(result, i + offset, true); continue; }
     BlobToRow(blob.data(), result, i + offset, cur);
   }
 }
@@ -309,7 +468,7 @@ template <bool NB>
 static unique_ptr<FunctionData> RingAggregateBind(ClientContext &, AggregateFunction &function,
                                                   vector<unique_ptr<Expression>> &) {
   function.return_type = TripleType(NB, /*aggregate_names=*/true);
-  return make_uniq<VariableReturnBindData>(function.return_type);
+  return make_uniq<RingBindData>(function.return_type);
 }
 
 // ---- scalar callbacks -----------------------------------------------------------------------------
@@ -324,16 +483,12 @@ static void LiftFunction(DataChunk &args, ExpressionState &, Vector &result) {
     if (IsNumeric(args.data[j].GetType())) num.push_back(FlatVector::GetData<float>(args.data[j]));
     else cat.push_back(FlatVector::GetData<int32_t>(args.data[j]));
   }
-  uint64_t need = 0;
-  std::vector<uint64_t> offs(rows + 1);
-  Check(cofactor_lift_host(num.data(), (int)num.size(), cat.data(), (int)cat.size(), rows,
-                           NB ? COFACTOR_NB : COFACTOR_TRIPLE, nullptr, 0, &need, nullptr));
-  std::vector<double> blobs(need);
-  Check(cofactor_lift_host(num.data(), (int)num.size(), cat.data(), (int)cat.size(), rows,
-                           NB ? COFACTOR_NB : COFACTOR_TRIPLE, blobs.data(), need, &need, offs.data()));
-  ListCursor cur;
+  // the expand kernel writes the result's child arrays (regular shape: one entry per sub-list)
+  const idx_t n = num.size(), m = cat.size();
   result.SetVectorType(VectorType::FLAT_VECTOR);
-  for (idx_t i = 0; i < rows; i++) BlobToRow(blobs.data() + offs[i], result, i, cur);
+  cofactor_tvec out;
+  ResultAsTvec(result, rows, n, m, NB, rows * m, NB ? 0 : rows * n * m, NB ? 0 : rows * m * (m + 1) / 2, out);
+  Check(cofactor_lift_host_tvec(Context(), num.data(), (int)n, cat.data(), (int)m, rows, NB ? COFACTOR_NB : COFACTOR_TRIPLE, &out));
 }
 
 // multiply_triple / multiply_nb_agg: Triple::MultiplyFunction (mul.cpp:19-611), multiply_nb (mul_nb.cpp:20-268)
@@ -342,19 +497,14 @@ static void MultiplyFunction(DataChunk &args, ExpressionState &, Vector &result)
   const idx_t rows = args.size();
   RecursiveFlatten(args.data[0], rows);
   RecursiveFlatten(args.data[1], rows);
-  ListCursor cur;
-  std::vector<double> a, b, out;
   result.SetVectorType(VectorType::FLAT_VECTOR);
-  for (idx_t i = 0; i < rows; i++) {
-    a.clear(); b.clear();
-    RowToBlob(args.data[0], i, NB, a);
-    RowToBlob(args.data[1], i, NB, b);
-    uint64_t need = 0;
-    Check(cofactor_triple_multiply(a.data(), a.size(), b.data(), b.size(), nullptr, 0, &need));
-    out.resize(need);
-    Check(cofactor_triple_multiply(a.data(), a.size(), b.data(), b.size(), out.data(), need, &need));
-    BlobToRow(out.data(), result, i, cur);
-  }
+  cofactor_tvec a, b, out;
+  VectorAsTvec(args.data[0], rows, NB, a);
+  VectorAsTvec(args.data[1], rows, NB, b);
+  uint64_t lc = 0, nc = 0, cc = 0;                    // two-call protocol: payload sizes first
+  Check(cofactor_multiply_host(Context(), &a, nullptr, &b, nullptr, rows, nullptr, &lc, &nc, &cc));
+  ResultAsTvec(result, rows, a.n + b.n, a.m + b.m, NB, lc, nc, cc, out);
+  Check(cofactor_multiply_host(Context(), &a, nullptr, &b, nullptr, rows, &out, nullptr, nullptr, nullptr));
 }
 
 template <bool NB>

@@ -225,8 +225,11 @@ public:
 struct ClientContext {};
 struct ExpressionState {};
 struct Expression {};
-struct AggregateInputData {};
-struct FunctionData { virtual ~FunctionData() {} };
+struct FunctionData {
+  virtual ~FunctionData() {}
+  template <class TARGET> TARGET &Cast() { return dynamic_cast<TARGET &>(*this); }
+};
+struct AggregateInputData { FunctionData *bind_data = nullptr; };   // (optional_ptr<FunctionData> in DuckDB)
 struct VariableReturnBindData : FunctionData {
   LogicalType stype;
   explicit VariableReturnBindData(LogicalType t) : stype(std::move(t)) {}

@@ -86,9 +86,12 @@ struct AggRun {
   std::vector<std::vector<data_t>> state_mem;   // one state per group
   AggregateInputData aid;
   ClientContext ctx;
-  AggRun(AggregateFunction &f, idx_t groups) : fn(f) {
+  std::shared_ptr<FunctionData> bind_data;      // one bind per query, shared by its threads' runs
+  AggRun(AggregateFunction &f, idx_t groups, std::shared_ptr<FunctionData> shared = nullptr) : fn(f) {
     vector<unique_ptr<Expression>> args;
-    auto bd = fn.bind(ctx, fn, args);
+    if (shared) bind_data = shared;
+    else bind_data = std::shared_ptr<FunctionData>(fn.bind(ctx, fn, args).release());
+    aid.bind_data = bind_data.get();
     result_type = fn.return_type;
     state_mem.assign(groups, std::vector<data_t>(fn.state_size(), 0xAB));
     for (auto &m : state_mem) fn.initialize(m.data());
@@ -183,7 +186,8 @@ int main() {
         out << ",\"" << pfx << "sum_group_by\":" << Rows(r, 2);
       }
       {  // two worker threads' local states combined into global ones (one of them empty for group 0)
-        AggRun global(fn33, 2), t1(fn33, 2), t2(fn33, 2);
+        AggRun global(fn33, 2);
+        AggRun t1(fn33, 2, global.bind_data), t2(fn33, 2, global.bind_data);
         auto c1 = Cols("abcdef", {0, 2, 3}, false);
         t1.Update(c1, {0, 1, 1});
         auto c2 = Cols("abcdef", {1, 4}, false);
@@ -211,6 +215,13 @@ int main() {
         run.Update(in, {0, 0, 1, 1, 1});
         Vector r = run.Finalize();
         out << ",\"" << pfx << "sum_lifted_group_by\":" << Rows(r, 2);
+        // ungrouped: the whole chunk of lifted triples into one state (the vector goes to the
+        // sum_triple kernels as it is, no per-row blobs)
+        AggRun one(sum, 1);
+        one.Update(in, {0, 0, 0, 0, 0});
+        one.Update(in, {0, 0, 0, 0, 0});
+        Vector r1 = one.Finalize();
+        out << ",\"" << pfx << "sum_lifted_all_twice\":" << Rows(r1, 1);
       }
       {  // multiply_triple(A, B): A = sum_to_triple_2_2(b,c,d,e) WHERE gb = 1, B = (a,c,d,f) WHERE gb = 2
         auto &fn22 = db.aggregates.at(nb ? "sum_to_nb_agg_2_2" : "sum_to_triple_2_2");

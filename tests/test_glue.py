@@ -46,6 +46,15 @@ def test_glue_callbacks_reproduce_reference_goldens(goldens, ref_table):
         assert doc[pfx + "sum_combined"] == grouped          # thread-local states combined
         # sum_triple(to_cofactor(..)) == sum_to_triple(..): same values, aggregate field names
         assert doc[pfx + "sum_lifted_group_by"] == grouped
+        # the ungrouped sum_triple over the same lifted chunk, fed twice: every value doubles
+        once = _expected(goldens, fname, 0)[0]
+        twice = doc[pfx + "sum_lifted_all_twice"][0]
+        assert twice["N"] == 2 * once["N"] and twice["lin_agg"] == [2 * v for v in once["lin_agg"]]
+        assert twice["quad_agg"] == [2 * v for v in once["quad_agg"]]
+        assert twice["lin_cat"] == [[dict(e, value=2 * e["value"]) for e in l] for l in once["lin_cat"]]
+        if not pfx:
+            assert twice["quad_cat"] == [[dict(e, value=2 * e["value"]) for e in l] for l in once["quad_cat"]]
+            assert twice["quad_num_cat"] == [[dict(e, value=2 * e["value"]) for e in l] for l in once["quad_num_cat"]]
     # scalars: test_lift.py / test_mul.py literals (lin_num / quad_num field names)
     assert doc["lift_all"] == _expected(goldens, "test_lift.py", 0)
     assert doc["nb_lift_all"] == _expected(goldens, "test_nb_lift.py", 0)
