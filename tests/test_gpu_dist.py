@@ -83,3 +83,66 @@ def test_two_ranks_allreduce_equals_whole_table(tmp_path, n, m, keys, nb):
             assert got == whole, name          # integer-valued table: exact in any merge order
         exchanged, aligned = np.load(os.path.join(str(tmp_path), "flags_%d.npy" % r))
         assert aligned == 1 and exchanged == 0   # the second round needed no key exchange
+
+
+def _mice_table(rows, lo, hi, device):
+    import torch
+    rng = np.random.default_rng(3)
+    x1 = rng.normal(size=rows).astype(np.float32)
+    x2 = rng.normal(size=rows).astype(np.float32)
+    k1 = (rng.integers(0, 4, rows) * 3 + 5).astype(np.int32)
+    k0 = ((((x1 + 0.5 * x2 + 0.3 * rng.normal(size=rows)) > 0).astype(np.int32) + (k1 > 8) * 2) * 10 + 1).astype(np.int32)
+    x0 = (2.0 * x1 - x2 + 0.7 * (k1 == 8) + 0.1 * rng.normal(size=rows)).astype(np.float32)
+    x0n, k0n = rng.random(rows) < 0.1, rng.random(rows) < 0.1
+    from cofactor_hip import mice
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(device)
+    return mice.MiceTable({"x0": d(np.where(x0n, np.float32(-999), x0)), "x1": d(x1), "x2": d(x2)},
+                          {"k0": d(np.where(k0n, np.int32(-999), k0)), "k1": d(k1)},
+                          {"x0": d(x0n.astype(np.uint8))}, {"k0": d(k0n.astype(np.uint8))})
+
+
+def _mice_worker(rank, world, port, rows, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "duckdb-imputation_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import cofactor_hip
+    from cofactor_hip import dist as cdist
+    from cofactor_hip import mice
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    device = torch.device("cuda", 0)
+    lo, hi = cdist.shard_bounds(rows, rank, world)
+    t = _mice_table(rows, lo, hi, device)
+    ctx = cofactor_hip.Context(0)
+    models = mice.run_mice(ctx, t, iterations=1, seed=3, dist=dist, device=device)
+    np.save(os.path.join(out_dir, "k0_%d.npy" % rank), models["k0"])
+    np.save(os.path.join(out_dir, "x0_%d.npy" % rank), models["x0"])
+    np.save(os.path.join(out_dir, "k0col_%d.npy" % rank), t.cat["k0"].cpu().numpy())
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mice_trains_the_models_of_the_single_process_run(tmp_path):
+    """The MICE loop over two row shards: every rank aggregates its shard, the all-reduced triple is
+    the whole table's, so both ranks train the single-process run's models and fill in the same
+    keys (the key column's fill is deterministic)."""
+    import torch
+    import cofactor_hip
+    from cofactor_hip import mice
+    rows, world = 120_000, 2
+    mp.spawn(_mice_worker, args=(world, _free_port(), rows, str(tmp_path)), nprocs=world, join=True)
+    t = _mice_table(rows, 0, rows, torch.device("cuda", 0))
+    ctx = cofactor_hip.Context(0)
+    models = mice.run_mice(ctx, t, iterations=1, seed=3)
+    k0 = t.cat["k0"].cpu().numpy()
+    ctx.close()
+    filled = []
+    for r in range(world):
+        for name in ("k0", "x0"):
+            got = np.load(os.path.join(str(tmp_path), "%s_%d.npy" % (name, r)))
+            assert np.allclose(got, models[name], rtol=1e-4, atol=1e-5), (name, r)
+        filled.append(np.load(os.path.join(str(tmp_path), "k0col_%d.npy" % r)))
+    assert np.array_equal(np.concatenate(filled), k0)
