@@ -243,29 +243,117 @@ void plan_cat_passes(const CatLayout &L, size_t lds_budget, std::vector<CatPass>
   if (cur_open) lds_passes.push_back(cur);
 }
 
+// grows a context scratch buffer (synchronises: kernels of earlier calls may still read the old one)
+template <typename T>
+cofactor_status scratch_reserve(cofactor_ctx *ctx, T *&buf, size_t &have, size_t need) {
+  if (need <= have) return COFACTOR_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(buf);
+  buf = nullptr;
+  have = 0;
+  HIP_TRY(hipMalloc((void **)&buf, need));
+  have = need;
+  return COFACTOR_OK;
+}
+
+// The generic categorical path.  Everything in one launch when all tables fit LDS together;
+// otherwise keys -> 16-bit codes once, then count / sum passes over column subsets and pair passes
+// over runs of pair tables (LDS), one launch per pair table that is too big for LDS (u32 cells in
+// HBM, the only table written in that launch).
 cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows,
                                bool timed = true, const uint8_t *mask = nullptr) {
-  hipStream_t st = a->ctx->stream;
+  cofactor_ctx *ctx = a->ctx;
+  hipStream_t st = ctx->stream;
+  const CatLayout &L = a->L;
   std::vector<CatPass> passes;
   CatPass hbm{};
   bool hbm_needed = false;
-  plan_cat_passes(a->L, a->ctx->lds_budget, passes, hbm, hbm_needed);
+  plan_cat_passes(L, ctx->lds_budget, passes, hbm, hbm_needed);
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (a->ctx->profiling && timed) {
+  if (ctx->profiling && timed) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    a->ctx->cat_ev.emplace_back(e0, e1);
+    ctx->cat_ev.emplace_back(e0, e1);
   }
-  const size_t launches = passes.size() + (hbm_needed ? 1 : 0);
-  size_t i = 0;
-  for (auto const &P : passes) {
-    HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, P, true, a->ctx->cat_grid, st,
-                                  i == 0 ? e0 : nullptr, i + 1 == launches ? e1 : nullptr, mask));
-    i++;
+  if (passes.size() == 1 && !hbm_needed)           // one launch does it all
+    return launch_cat_accumulate(num, cat, rows, L, a->D, passes[0], true, ctx->cat_grid, st, e0, e1, mask) == hipSuccess
+               ? COFACTOR_OK : hip_fail(hipGetLastError(), "cat_accumulate");
+  // a column whose own count + sum tables exceed LDS: counts and sums with global atomics (old path)
+  const bool do_s = L.kind == 0 && L.n > 0;
+  bool sums_fit = true;
+  for (int c = 0; c < L.m; c++) sums_fit = sums_fit && cat_sums_lds_bytes(L, 1u << c, do_s) <= ctx->lds_budget;
+  if (e0) HIP_TRY(hipEventRecord(e0, st));
+  const uint64_t piece = 1ull << 27;               // rows per code-cache fill
+  for (uint64_t off = 0; off < rows; off += piece) {
+    const uint64_t prows = std::min(piece, rows - off), stride = (prows + 3) / 4 * 4;
+    NumCols pn = num;
+    CatCols pc = cat;
+    for (int k = 0; k < L.n; k++) pn.p[k] = num.p[k] + off;
+    for (int c = 0; c < L.m; c++) pc.p[c] = cat.p[c] + off;
+    const uint8_t *pmask = mask ? mask + off : nullptr;
+    cofactor_status s = scratch_reserve(ctx, ctx->code_cache, ctx->code_cache_bytes, (size_t)L.m * stride * 2);
+    if (s != COFACTOR_OK) return s;
+    HIP_TRY(launch_cat_codes(pc, prows, stride, L, a->D, pmask, ctx->code_cache, st));
+    if (sums_fit) {
+      unsigned sub = 0;
+      size_t used = 0;
+      for (int c = 0; c < L.m; c++) {
+        const size_t b = cat_sums_lds_bytes(L, 1u << c, do_s);
+        if (sub && used + b > ctx->lds_budget) {
+          HIP_TRY(launch_cat_sums(pn, ctx->code_cache, prows, stride, L, a->D, sub, ctx->cat_grid, st));
+          sub = 0; used = 0;
+        }
+        sub |= 1u << c; used += b;
+      }
+      if (sub) HIP_TRY(launch_cat_sums(pn, ctx->code_cache, prows, stride, L, a->D, sub, ctx->cat_grid, st));
+    } else {
+      CatPass base{};
+      base.do_cnt = 1; base.do_s = L.kind == 0;
+      base.col_mask = (L.m >= 32) ? 0xFFFFFFFFu : ((1u << L.m) - 1u);
+      base.dict_lds = hbm.dict_lds;
+      HIP_TRY(launch_cat_accumulate(pn, pc, prows, L, a->D, base, false, ctx->cat_grid, st, nullptr, nullptr, pmask));
+    }
+    if (L.kind == 0) {
+      // pair tables: runs that fit LDS together, then the big ones one by one
+      const int npairs = L.m * (L.m + 1) / 2;
+      CatPass run{};
+      size_t used = 0;
+      std::vector<int> big;
+      auto flush = [&]() -> hipError_t {
+        if (run.p_cells == 0) return hipSuccess;
+        hipError_t e = launch_cat_pairs(ctx->code_cache, prows, stride, L, a->D, run, nullptr, ctx->cat_grid, st);
+        run = CatPass{};
+        used = 0;
+        return e;
+      };
+      int q = 0;
+      for (int c1 = 0; c1 < L.m; c1++)
+        for (int c2 = c1; c2 < L.m && q < npairs; c2++, q++) {
+          const size_t bytes = (size_t)L.kc[c1] * (size_t)L.kc[c2] * 4;
+          if (bytes > ctx->lds_budget) { HIP_TRY(flush()); big.push_back(q); continue; }
+          if (used + bytes > ctx->lds_budget) HIP_TRY(flush());
+          if (run.p_cells == 0) run.p_base = L.p_off[q];
+          run.pair_mask[q >> 5] |= 1u << (q & 31);
+          run.p_cells += (int)(bytes / 4);
+          used += bytes;
+        }
+      HIP_TRY(flush());
+      for (int qb : big) {
+        int c1 = 0, rem = qb;
+        while (rem >= L.m - c1) { rem -= L.m - c1; c1++; }
+        const int c2 = c1 + rem;
+        const size_t cells = (size_t)L.kc[c1] * (size_t)L.kc[c2];
+        s = scratch_reserve(ctx, ctx->pair_tmp, ctx->pair_tmp_bytes, cells * 4);
+        if (s != COFACTOR_OK) return s;
+        HIP_TRY(hipMemsetAsync(ctx->pair_tmp, 0, cells * 4, st));
+        CatPass one{};
+        one.pair_mask[qb >> 5] |= 1u << (qb & 31);
+        HIP_TRY(launch_cat_pairs(ctx->code_cache, prows, stride, L, a->D, one, ctx->pair_tmp, ctx->cat_grid, st));
+        HIP_TRY(launch_cat_fold_u32(ctx->pair_tmp, (long long)cells, a->D.p + L.p_off[qb], st));
+      }
+    }
   }
-  if (hbm_needed)
-    HIP_TRY(launch_cat_accumulate(num, cat, rows, a->L, a->D, hbm, false, a->ctx->cat_grid, st,
-                                  i == 0 ? e0 : nullptr, e1, mask));
+  if (e1) HIP_TRY(hipEventRecord(e1, st));
   return COFACTOR_OK;
 }
 
@@ -652,6 +740,8 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->pair_slabs);
   (void)hipFree(ctx->skip);
   (void)hipFree(ctx->ring_red);
+  (void)hipFree(ctx->code_cache);
+  (void)hipFree(ctx->pair_tmp);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -509,4 +509,207 @@ hipError_t launch_cat_tables_import(const CatLayout &L, const CatDevice &D, cons
   return hipGetLastError();
 }
 
+// ---- multi-pass generic path with a code cache ---------------------------------------------------------
+// When the tables of an update do not fit LDS together, the keys are translated ONCE into 16-bit
+// codes ([column][row], 0xFFFF = row dropped / key unknown) and every later pass reads those: 2 bytes
+// per key instead of 4, no dictionary probes, four rows per thread.
+//   cat_codes_kernel   keys -> codes
+//   cat_sums_kernel    key counts + per-key sums of a subset of the key columns (LDS tables)
+//   cat_pairs_kernel   pair tables of a run of column pairs (LDS tables), or ONE pair table too big
+//                      for LDS as u32 cells in HBM: it is the only table written in that launch, so it
+//                      stays in L2 / MALL (1 M cells = 4 MB) instead of 55 tables thrashing HBM
+constexpr unsigned short CODE_NONE = 0xFFFFu;
+
+__global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t rows, uint64_t stride, CatLayout L, CatDevice D,
+                                                        const uint8_t *__restrict__ mask, unsigned short *__restrict__ codes) {
+  // four rows per thread, one column at a time: 16-B key loads, 8-B code stores
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const uint64_t nq = (rows + 3) / 4;
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = 4 * q;
+    const int cnt = (int)min<uint64_t>(4, rows - r);
+    unsigned keep = 0xF;
+    if (mask) { keep = 0; for (int e = 0; e < cnt; e++) keep |= (mask[r + e] != 0) << e; }
+    for (int c = 0; c < L.m; c++) {
+      const int32_t *col = cat.p[c];
+      i32x4 kv = {0, 0, 0, 0};
+      if (cnt == 4 && (reinterpret_cast<uintptr_t>(col) & 15) == 0) kv = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(col + r));
+      else for (int e = 0; e < cnt; e++) kv[e] = col[r + e];
+      unsigned short out[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        out[e] = CODE_NONE;
+        if (e < cnt && ((keep >> e) & 1)) {
+          const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], kv[e]);
+          if (code < 0 || code >= L.kc[c] || code >= 0xFFFF) D.flags[1] = 1;
+          else out[e] = (unsigned short)code;
+        }
+      }
+      // stride is a multiple of 4: the store is 8-byte aligned
+      *reinterpret_cast<uint2 *>(codes + (uint64_t)c * stride + r) = make_uint2(out[0] | ((unsigned)out[1] << 16), out[2] | ((unsigned)out[3] << 16));
+    }
+  }
+}
+
+// counts and sums of the key columns in col_mask (their tables: cnt u32 [kc], then s f64 [kc][n])
+__global__ __launch_bounds__(CAT_THREADS) void cat_sums_kernel(NumCols num, const unsigned short *__restrict__ codes, uint64_t rows,
+                                                               uint64_t stride, CatLayout L, CatDevice D, unsigned col_mask,
+                                                               int do_s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  // LDS carve: sums first (8-byte aligned), then counts
+  __shared__ int s_base[COFACTOR_MAX_CAT], c_base[COFACTOR_MAX_CAT];
+  __shared__ int tot_s, tot_c;
+  const int n = L.n, m = L.m, tid = threadIdx.x;
+  if (tid == 0) {
+    int so = 0, co = 0;
+    for (int c = 0; c < m; c++)
+      if ((col_mask >> c) & 1u) { s_base[c] = so; c_base[c] = co; so += do_s ? L.kc[c] * n : 0; co += L.kc[c]; }
+    tot_s = so; tot_c = co;
+  }
+  __syncthreads();
+  double *l_s = reinterpret_cast<double *>(lds_raw);
+  unsigned *l_c = reinterpret_cast<unsigned *>(l_s + tot_s);
+  for (int i = tid; i < tot_s; i += CAT_THREADS) l_s[i] = 0.0;
+  for (int i = tid; i < tot_c; i += CAT_THREADS) l_c[i] = 0u;
+  __syncthreads();
+  const uint64_t step = (uint64_t)gridDim.x * CAT_THREADS;
+  for (uint64_t r = (uint64_t)blockIdx.x * CAT_THREADS + tid; r < rows; r += step) {
+    float x[COFACTOR_MAX_NUM];
+    if (do_s)
+#pragma unroll
+      for (int k = 0; k < COFACTOR_MAX_NUM; k++)
+        if (k < n) x[k] = num.p[k][r];
+    for (int c = 0; c < m; c++) {
+      if (!((col_mask >> c) & 1u)) continue;
+      const unsigned code = codes[(uint64_t)c * stride + r];
+      if (code == CODE_NONE) continue;
+      atomicAdd(&l_c[c_base[c] + code], 1u);
+      if (do_s) {
+        double *row = l_s + s_base[c] + (int)code * n;
+#pragma unroll
+        for (int k = 0; k < COFACTOR_MAX_NUM; k++)
+          if (k < n) unsafeAtomicAdd(&row[k], (double)x[k]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < m; c++) {
+    if (!((col_mask >> c) & 1u)) continue;
+    for (int i = tid; i < L.kc[c]; i += CAT_THREADS)
+      if (l_c[c_base[c] + i]) atomicAdd(&D.cnt[L.cnt_off[c] + i], (unsigned long long)l_c[c_base[c] + i]);
+    if (do_s)
+      for (int i = tid; i < L.kc[c] * n; i += CAT_THREADS)
+        if (l_s[s_base[c] + i] != 0.0) unsafeAtomicAdd(&D.s[L.s_off[c] + i], l_s[s_base[c] + i]);
+  }
+}
+
+// pair tables of the pairs in P.pair_mask.  LDS_TABLES: u32 cells in LDS covering D.p cells
+// [P.p_base, P.p_base + P.p_cells), added to D.p at the end.  Otherwise exactly one pair, u32
+// cells in `gtab` (zeroed by the caller, folded into D.p by cat_fold_u32_kernel).
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(CAT_THREADS) void cat_pairs_kernel(const unsigned short *__restrict__ codes, uint64_t rows,
+                                                                uint64_t stride, CatLayout L, CatDevice D, CatPass P,
+                                                                unsigned *__restrict__ gtab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned *l_p = reinterpret_cast<unsigned *>(lds_raw);
+  const int m = L.m, tid = threadIdx.x;
+  if (LDS_TABLES) {
+    for (int i = tid; i < P.p_cells; i += CAT_THREADS) l_p[i] = 0u;
+    __syncthreads();
+  }
+  const int npairs = m * (m + 1) / 2;
+  const uint64_t nq = (rows + 3) / 4, step = (uint64_t)gridDim.x * CAT_THREADS;
+  for (uint64_t qd = (uint64_t)blockIdx.x * CAT_THREADS + tid; qd < nq; qd += step) {
+    const uint64_t r = 4 * qd;
+    int q = 0;
+    for (int c1 = 0; c1 < m; c1++) {
+      uint2 a = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      bool a_loaded = false;
+      for (int c2 = c1; c2 < m; c2++, q++) {
+        if (!((P.pair_mask[q >> 5] >> (q & 31)) & 1u)) continue;
+        if (!a_loaded) { a = *reinterpret_cast<const uint2 *>(codes + (uint64_t)c1 * stride + r); a_loaded = true; }
+        const uint2 b = c2 == c1 ? a : *reinterpret_cast<const uint2 *>(codes + (uint64_t)c2 * stride + r);
+        const int off = LDS_TABLES ? L.p_off[q] - P.p_base : 0;
+        const int kc2 = L.kc[c2];
+        const unsigned ca[4] = {a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, a.y >> 16};
+        const unsigned cb[4] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (ca[e] != CODE_NONE && cb[e] != CODE_NONE) {       // (rows past the end hold CODE_NONE)
+            const unsigned idx = off + ca[e] * kc2 + cb[e];
+            if (LDS_TABLES) atomicAdd(&l_p[idx], 1u);
+            else atomicAdd(&gtab[idx], 1u);
+          }
+      }
+    }
+    (void)npairs;
+  }
+  if (LDS_TABLES) {
+    __syncthreads();
+    for (int i = tid; i < P.p_cells; i += CAT_THREADS)
+      if (l_p[i]) atomicAdd(&D.p[P.p_base + i], (unsigned long long)l_p[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cat_fold_u32_kernel(const unsigned *__restrict__ src, long long cells,
+                                                           unsigned long long *__restrict__ dst) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x)
+    if (src[i]) dst[i] += src[i];
+}
+
+hipError_t launch_cat_codes(const CatCols &cat, uint64_t rows, uint64_t stride, const CatLayout &L, const CatDevice &D,
+                            const uint8_t *mask, unsigned short *codes, hipStream_t stream) {
+  if (rows == 0 || L.m == 0) return hipSuccess;
+  const uint64_t nq = (rows + 3) / 4;
+  const int grid = (int)std::min<uint64_t>((nq + 255) / 256, 8192);
+  hipLaunchKernelGGL(cat_codes_kernel, dim3(grid), dim3(256), 0, stream, cat, rows, stride, L, D, mask, codes);
+  return hipGetLastError();
+}
+
+size_t cat_sums_lds_bytes(const CatLayout &L, unsigned col_mask, bool do_s) {
+  size_t b = 0;
+  for (int c = 0; c < L.m; c++)
+    if ((col_mask >> c) & 1u) b += (size_t)L.kc[c] * 4 + (do_s ? (size_t)L.kc[c] * L.n * 8 : 0);
+  return b;
+}
+
+hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
+                           const CatLayout &L, const CatDevice &D, unsigned col_mask, int grid, hipStream_t stream) {
+  if (rows == 0 || col_mask == 0) return hipSuccess;
+  const bool do_s = L.kind == 0 && L.n > 0;
+  const size_t lds = cat_sums_lds_bytes(L, col_mask, do_s);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)cat_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
+  if ((uint64_t)grid > need) grid = (int)need;
+  hipLaunchKernelGGL(cat_sums_kernel, dim3(grid), dim3(CAT_THREADS), lds, stream, num, codes, rows, stride, L, D, col_mask, do_s ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_pairs(const unsigned short *codes, uint64_t rows, uint64_t stride, const CatLayout &L, const CatDevice &D,
+                            const CatPass &P, unsigned *gtab, int grid, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  const uint64_t need = ((rows + 3) / 4 + CAT_THREADS - 1) / CAT_THREADS;
+  if ((uint64_t)grid > need) grid = (int)need;
+  if (gtab) {
+    hipLaunchKernelGGL((cat_pairs_kernel<false>), dim3(grid), dim3(CAT_THREADS), 0, stream, codes, rows, stride, L, D, P, gtab);
+  } else {
+    const size_t lds = (size_t)P.p_cells * 4;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)cat_pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((cat_pairs_kernel<true>), dim3(grid), dim3(CAT_THREADS), lds, stream, codes, rows, stride, L, D, P, gtab);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_fold_u32(const unsigned *src, long long cells, unsigned long long *dst, hipStream_t stream) {
+  if (cells == 0) return hipSuccess;
+  hipLaunchKernelGGL(cat_fold_u32_kernel, dim3((unsigned)std::min<long long>((cells + 255) / 256, 4096)), dim3(256), 0, stream, src, cells, dst);
+  return hipGetLastError();
+}
+
 }  // namespace cofactor

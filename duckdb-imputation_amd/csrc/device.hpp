@@ -116,6 +116,18 @@ hipError_t launch_cat_rehash(const CatLayout &Lold, const CatDevice &Dold, const
 hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,
                                const CatDevice &Dnew, hipStream_t stream);
 
+// Multi-pass generic path: keys -> 16-bit codes once ([column][stride], stride = rows rounded up to 4),
+// then count / sum passes over column subsets and pair passes that read the codes (cat.hip).
+hipError_t launch_cat_codes(const CatCols &cat, uint64_t rows, uint64_t stride, const CatLayout &L, const CatDevice &D,
+                            const uint8_t *mask, unsigned short *codes, hipStream_t stream);
+size_t cat_sums_lds_bytes(const CatLayout &L, unsigned col_mask, bool do_s);
+hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
+                           const CatLayout &L, const CatDevice &D, unsigned col_mask, int grid, hipStream_t stream);
+// gtab == nullptr: LDS tables for the pairs of P (cells [p_base, p_base + p_cells)); else ONE pair, u32 cells in gtab
+hipError_t launch_cat_pairs(const unsigned short *codes, uint64_t rows, uint64_t stride, const CatLayout &L, const CatDevice &D,
+                            const CatPass &P, unsigned *gtab, int grid, hipStream_t stream);
+hipError_t launch_cat_fold_u32(const unsigned *src, long long cells, unsigned long long *dst, hipStream_t stream);
+
 // Dictionary-aligned table seam (multi-GPU): re-index tables by a code remap, and the tables as one
 // array of doubles [cnt | s | p] (n_cnt + n_s + n_p values) for a single all-reduce.
 hipError_t launch_cat_remap(const CatLayout &Lold, const CatDevice &Dold, const CatLayout &Lnew,

@@ -36,6 +36,12 @@ struct cofactor_ctx {
   size_t skip_bytes = 0;
   size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
   double *ring_red = nullptr;   // 256 doubles: reduced dense children of a vector of triples (sum_triple)
+  // multi-pass generic path: 16-bit key codes of the batch ([column][stride]) and the u32 cells of a
+  // pair table too big for LDS
+  unsigned short *code_cache = nullptr;
+  size_t code_cache_bytes = 0;
+  unsigned *pair_tmp = nullptr;
+  size_t pair_tmp_bytes = 0;
 };
 
 #define CTX_LOCK(ctxp) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxp)->mu)
