@@ -237,7 +237,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "%s_%d_%d" % (kname, n, m)
+                key = "%s%s_%d_%d" % (kname, "_nb" if args.nb else "", n, m)
                 # the committed PMC figure is per launch at the row count it was measured with
                 if tj.get(key + "__rows") == rows:
                     traffic = tj.get(key)

@@ -17,7 +17,7 @@ import json
 import os
 import sys
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.environ.get("PROFILES_OUT") or os.path.dirname(os.path.abspath(__file__))   # PROFILES_OUT: write the summaries elsewhere
 
 
 def short(name):
@@ -33,8 +33,8 @@ def find(d, suffix):
 def main():
     rnd, prof, fetch, write = sys.argv[1:5]
     tag = ("_" + sys.argv[5]) if len(sys.argv) > 5 else ""
-    key = sys.argv[6] if len(sys.argv) > 6 else None
-    nrows = int(float(sys.argv[7])) if len(sys.argv) > 7 else None
+    key = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] else None
+    nrows = int(float(sys.argv[7])) if len(sys.argv) > 7 and sys.argv[7] else None
     stats = find(prof, "_kernel_stats.csv")
     rows = list(csv.DictReader(open(stats)))
     out = os.path.join(HERE, "%s_kernel_stats%s.csv" % (rnd, tag))

@@ -8,3 +8,4 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $R/gpurun_out/${TAG}_sq_a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calibration --no-check "$@" > $R/gpurun_out/${TAG}_sq_a.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_I8 --output-format csv -d $R/gpurun_out/${TAG}_sq_b -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calibration --no-check "$@" > $R/gpurun_out/${TAG}_sq_b.log 2>&1 || exit 1
 python3 $R/tests/tools/sq_summary.py $R/gpurun_out/${TAG}_sq.json "$KSUB" $R/gpurun_out/${TAG}_sq_a $R/gpurun_out/${TAG}_sq_b
+rm -rf $R/gpurun_out/${TAG}_sq_a $R/gpurun_out/${TAG}_sq_b $R/gpurun_out/${TAG}_sq_a.log $R/gpurun_out/${TAG}_sq_b.log
