@@ -33,7 +33,7 @@ SYMBOLS = [
     "cofactor_groups_create", "cofactor_groups_destroy", "cofactor_groups_update_device",
     "cofactor_groups_update_host", "cofactor_groups_count", "cofactor_groups_combine",
     "cofactor_groups_finalize", "cofactor_groups_to_tvec",
-    "cofactor_blob_len",
+    "cofactor_blob_len", "cofactor_triple_to_text", "cofactor_triple_from_text",
     "cofactor_linreg_train", "cofactor_lda_train",
     "cofactor_linreg_predict_device", "cofactor_lda_predict_device",
     "cofactor_linreg_predict_host", "cofactor_lda_predict_host",
@@ -99,6 +99,8 @@ def lib():
             getattr(L, f).argtypes = [vp, u64, vp, u64, vp, u64, pu64]
         L.cofactor_blob_len.argtypes = [vp, u64]
         L.cofactor_blob_len.restype = u64
+        L.cofactor_triple_to_text.argtypes = [vp, u64, C.c_int32, vp, u64, pu64]
+        L.cofactor_triple_from_text.argtypes = [C.c_char_p, u64, vp, u64, pu64]
         i32, f32 = C.c_int32, C.c_float
         L.cofactor_linreg_train.argtypes = [vp, u64, i32, f32, f32, i32, i32, i32, vp, u64, pu64]
         L.cofactor_lda_train.argtypes = [vp, u64, i32, f32, i32, vp, u64, pu64]
@@ -443,6 +445,21 @@ def lda_train(triple, label, shrinkage=0.0, normalize=False):
     """lda_train(triple, label, shrinkage, normalize) -> float32 parameter vector (host)."""
     b = np.ascontiguousarray(triple, dtype=np.float64)
     return _two_call_f32(lib().cofactor_lda_train, b.ctypes.data, b.size, label, shrinkage, int(normalize))
+
+
+def to_text(blob, aggregate_names=True):
+    """The triple as DuckDB's STRUCT literal text (what the reference's MICE drivers paste into SQL)."""
+    b = np.ascontiguousarray(blob, dtype=np.float64)
+    need = C.c_uint64(0)
+    _check(lib().cofactor_triple_to_text(b.ctypes.data, b.size, int(aggregate_names), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _check(lib().cofactor_triple_to_text(b.ctypes.data, b.size, int(aggregate_names), buf, need.value, C.byref(need)))
+    return buf.value.decode()
+
+
+def from_text(text):
+    raw = text.encode()
+    return _two_call(lib().cofactor_triple_from_text, raw, len(raw))
 
 
 def blob_len(blob):

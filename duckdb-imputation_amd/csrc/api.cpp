@@ -1383,6 +1383,31 @@ cofactor_status cofactor_triple_sub(const double *a, uint64_t a_len, const doubl
 
 uint64_t cofactor_blob_len(const double *blob, uint64_t cap) { return blob_len(blob, cap); }
 
+cofactor_status cofactor_triple_to_text(const double *blob, uint64_t blob_len_, int32_t aggregate_names, char *out,
+                                        uint64_t cap, uint64_t *needed) {
+  if (!blob) return fail(COFACTOR_ERR_INVALID, "null argument");
+  ListTriple t;
+  std::string err;
+  if (!blob_decode(blob, blob_len_, t, err)) return fail(COFACTOR_ERR_INVALID, err);
+  const std::string text = triple_to_text(t, aggregate_names != 0);
+  if (needed) *needed = text.size() + 1;
+  if (!out) return COFACTOR_OK;
+  if (cap < text.size() + 1) return fail(COFACTOR_ERR_CAPACITY, "output buffer too small");
+  std::memcpy(out, text.c_str(), text.size() + 1);
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_triple_from_text(const char *text, uint64_t text_len, double *out, uint64_t cap,
+                                          uint64_t *needed) {
+  if (!text) return fail(COFACTOR_ERR_INVALID, "null argument");
+  ListTriple t;
+  std::string err;
+  if (!triple_from_text(text, (size_t)text_len, t, err)) return fail(COFACTOR_ERR_INVALID, err);
+  std::vector<double> blob;
+  blob_encode(t, blob);
+  return emit_blob(blob, out, cap, needed);
+}
+
 // ---- consumers of the triple ----------------------------------------------------------------------
 
 static cofactor_status emit_floats(const std::vector<float> &v, float *out, uint64_t cap,

@@ -6,26 +6,28 @@
 //
 // Reference loops replaced: duckdb_extension/src/triple/sum/sum_no_lift.cpp:119-214.
 //
-// Workgroup = 512 threads = two teams of 4 waves working on 256-row tiles, double-buffered in LDS:
-// while the MFMA team (waves 4-7) eats tile k, the loader team (waves 0-3) counts tile k and
-// prepares tile k+1 in the other buffer, so the LDS-atomic work and the matrix work of one CU
-// overlap by construction (one barrier per tile).
-//   loaders  park whole columns: float columns go to the Gram tile xt[col][row]; key columns are
-//            looked up in the LDS copy of the column's dictionary and their codes go to
-//            codes[col][row] (u16).  Then, one thread per row: m count increments (ds_add_u32)
-//            and m(m-1)/2 pair-count increments into LDS tables whose cells are 16 bit wide, two
-//            per dword (half the LDS); every 240 tiles, before a cell can wrap, the team adds the
-//            pair table into the workgroup's private slab in HBM (no contention).
-//   MFMA team each wave, for its 64 rows: the dense Gram with one v_mfma_f32_4x4x1_16b_f32 per
-//            row (as gram.hip), and the per-key sums as ONE-HOT x PIECES products on
-//            v_mfma_f32_32x32x16_bf16: A = one-hot(code) of two key columns (32 rows of A =
-//            2 x 16 codes), B = x split exactly into three bf16 pieces (x = hi + mid + lo, 3n <= 32
-//            piece columns per block), K = 16 table rows.  1.0 x piece is exact, accumulation is
-//            fp32 and is folded into the fp64 LDS table every 8 tiles, so the sums carry the
-//            same error bound as the dense path.
-// At the end the count / sum tables are added to the aggregate's HBM tables with global atomics,
-// the pair slabs are folded by fused_pairs_fold_kernel, and the Gram image goes through the same
-// partials + gram_fold_kernel path as gram.hip.
+// Workgroup = 768 threads = THREE teams of 4 waves that meet at ONE barrier per 256-row tile, on tiles
+// double-buffered in LDS, so loading, LDS-atomic work and matrix work of one CU overlap:
+//   loaders   (waves 0-3) keep two tiles of 16-byte non-temporal loads in flight (register ring) and
+//             park whole columns: float columns go to the Gram tile xt[col][row] and, split exactly
+//             into three bf16 pieces (x = hi + mid + lo), to pt[piece * n + col][row]; key columns
+//             are translated to codes (byte table in LDS for keys 0..255, else the LDS copy of the
+//             column's hash dictionary) and go to codes[col][row] (u16);
+//   counters  (waves 4-7), one thread per row: the m(m-1)/2 off-diagonal pair increments as
+//             ds_add_u32 into pair tables in LDS (ONE u32 cell per key pair), flushed once at the end
+//             into the workgroup's private slab in HBM; key counts and the diagonal pairs are row
+//             sums of pair table (c, c+1) and are filled in by fused_pairs_fold_kernel (a single key
+//             column counts in the row loop);
+//   MFMA team (waves 8-11), 64 rows per wave: the dense Gram with v_mfma_f32_4x4x1_16b_f32 (as
+//             gram.hip), and the per-key sums as ONE-HOT x PIECES products on
+//             v_mfma_f32_32x32x16_bf16: A = one-hot(code) of two key columns (32 rows of A =
+//             2 x 16 codes), B = the <= 32 piece columns, K = 16 table rows.  1.0 x piece is exact,
+//             accumulation is fp32 and is folded into the fp64 LDS table every S_FLUSH_TILES = 32
+//             tiles (the chains add bf16 pieces, 8-bit mantissas: all but exact, guarded by a test).
+// At the end the sum tables are added to the aggregate's HBM tables with global atomics, the pair
+// slabs are folded by fused_pairs_fold_kernel, and the Gram image goes through the same partials +
+// gram_fold_kernel path as gram.hip.  (fused2.hip is the LDS-DMA / all-MFMA variant that also takes
+// NB aggregates and n = 0; this kernel is the faster one on the shapes it takes.)
 #include "device.hpp"
 
 namespace cofactor {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   unsigned long long *l_slot = reinterpret_cast<unsigned long long *>(lds + cv.slot);
   int32_t *l_dcode = reinterpret_cast<int32_t *>(lds + cv.dcode);
   unsigned *l_cnt = reinterpret_cast<unsigned *>(lds + cv.cnt);
-  unsigned *l_p = reinterpret_cast<unsigned *>(lds + cv.pairs);   // two 16-bit cells per dword
+  unsigned *l_p = reinterpret_cast<unsigned *>(lds + cv.pairs);   // one u32 cell per key pair
   unsigned *l_nf = reinterpret_cast<unsigned *>(lds + cv.nf);     // [buffer]: stamp of a tile holding inf / nan
   unsigned *l_skip = l_nf + 2;                                    // [buffer]: stamp of a tile with an unknown key
   unsigned char *l_direct = lds + cv.direct;                      // [column][key 0..255] -> code (NO_CODE if absent)
@@ -221,11 +223,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_kernel(NumCols num, CatCo
   auto fetch = [&](uint4 (&pre)[LDX], unsigned &pre_mask, uint64_t t) {
     const uint64_t r0 = t * TR + 4 * (uint64_t)lane;
     // row filter of this lane's 4 rows, one byte each (the launcher checked the 4-byte alignment)
-    // (without a filter the same load reads 4 bytes of column 0 and is ignored: see below)
-    const uint8_t *mbase = mask ? mask : reinterpret_cast<const uint8_t *>(n ? (const void *)num.p[0] : (const void *)cat.p[0]);
+    // (without a filter the same instruction re-reads the first 256 bytes of column 0 — always the
+    // same cache line, no HBM traffic — and the word is ignored: the number of loads per call stays
+    // fixed, see below)
+    const uint8_t *mbase = mask ? mask + r0 : reinterpret_cast<const uint8_t *>(n ? (const void *)num.p[0] : (const void *)cat.p[0]) + 4 * lane;
     // raw word: park() decides whether it means anything (a select here would make the wave wait
     // for this load, and so for every older load of the ring, right after issuing it)
-    pre_mask = *reinterpret_cast<const unsigned *>(mbase + r0);
+    pre_mask = *reinterpret_cast<const unsigned *>(mbase);
     // Every slot loads, a slot past the last column re-reads the last one: a fixed number of
     // loads per call lets the compiler wait with vmcnt(N) for the tile it parks and leave the
     // younger tile's loads in flight (a conditional load forces vmcnt(0), i.e. a ring of one).
@@ -660,10 +664,7 @@ bool fused_applicable(const CatLayout &L, const int32_t *nkeys, size_t lds_limit
 }
 
 int fused_grid(const CatLayout &L, int cus, int partials_cap_wgs, uint64_t rows) {
-  const FusedCarve cv = make_carve(L, (L.n + 3) / 4);
-  int per_cu = (int)((160 * 1024) / (size_t)cv.total);
-  per_cu = 1;                                               // 12 waves of up to 168 registers fill a CU
-  int grid = cus * per_cu;
+  int grid = cus;                                           // 12 waves of up to 168 registers and ~159 KB of LDS fill a CU
   if (grid > partials_cap_wgs) grid = partials_cap_wgs;
   const uint64_t ntiles = rows / TR;
   if ((uint64_t)grid > ntiles) grid = (int)ntiles;

@@ -2,7 +2,11 @@
 #include "triple.hpp"
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 namespace cofactor {
 
@@ -90,6 +94,194 @@ void blob_encode(const ListTriple &t, std::vector<double> &out) {
     out.push_back((double)lst.size());
     for (auto const &e : lst) { out.push_back(e.k1); out.push_back(e.k2); out.push_back(e.val); }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+void put_number(std::string &out, double v, bool as_float) {
+  char buf[40];
+  if (!as_float) { snprintf(buf, sizeof buf, "%lld", (long long)v); out += buf; return; }
+  if (std::isnan(v)) { out += "nan"; return; }
+  if (std::isinf(v)) { out += v > 0 ? "inf" : "-inf"; return; }
+  for (int prec = 6; prec <= 17; prec++) {            // shortest form that reads back as the same double
+    snprintf(buf, sizeof buf, "%.*g", prec, v);
+    if (strtod(buf, nullptr) == v) break;
+  }
+  out += buf;
+  if (!strpbrk(buf, ".eEn")) out += ".0";             // 15 -> 15.0, as DuckDB prints a FLOAT
+}
+
+struct TextCursor {
+  const char *p, *end;
+  std::string *err;
+  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+  bool eat(char c) { ws(); if (p < end && *p == c) { p++; return true; } return false; }
+  bool need(char c) { if (eat(c)) return true; *err = std::string("triple text: expected '") + c + "'"; return false; }
+  bool name(std::string &out) {
+    ws();
+    if (p >= end || (*p != '\'' && *p != '"')) { *err = "triple text: expected a quoted field name"; return false; }
+    const char q = *p++;
+    const char *s0 = p;
+    while (p < end && *p != q) p++;
+    if (p >= end) { *err = "triple text: unterminated field name"; return false; }
+    out.assign(s0, p++);
+    return true;
+  }
+  bool number(double &v) {
+    ws();
+    if (end - p >= 3 && !strncmp(p, "nan", 3)) { v = std::nan(""); p += 3; return true; }
+    if (end - p >= 3 && !strncmp(p, "inf", 3)) { v = INFINITY; p += 3; return true; }
+    if (end - p >= 4 && !strncmp(p, "-inf", 4)) { v = -INFINITY; p += 4; return true; }
+    std::string tok;
+    while (p < end && (isdigit((unsigned char)*p) || *p == '-' || *p == '+' || *p == '.' || *p == 'e' || *p == 'E')) tok += *p++;
+    if (tok.empty()) { *err = "triple text: expected a number"; return false; }
+    char *stop = nullptr;
+    v = strtod(tok.c_str(), &stop);
+    if (!stop || *stop) { *err = "triple text: malformed number '" + tok + "'"; return false; }
+    return true;
+  }
+  // [ number, ... ]
+  bool numbers(std::vector<double> &out) {
+    out.clear();
+    if (!need('[')) return false;
+    if (eat(']')) return true;
+    do { double v; if (!number(v)) return false; out.push_back(v); } while (eat(','));
+    return need(']');
+  }
+  // { 'a': number, 'b': number [, 'c': number] } with the given field names, in any order
+  bool record(const char *const *names, int count, double *vals) {
+    if (!need('{')) return false;
+    bool seen[3] = {false, false, false};
+    do {
+      std::string nm;
+      if (!name(nm) || !need(':')) return false;
+      int idx = -1;
+      for (int i = 0; i < count; i++) if (nm == names[i]) idx = i;
+      if (idx < 0) { *err = "triple text: unexpected field '" + nm + "'"; return false; }
+      if (!number(vals[idx])) return false;
+      seen[idx] = true;
+    } while (eat(','));
+    for (int i = 0; i < count; i++) if (!seen[i]) { *err = std::string("triple text: missing field '") + names[i] + "'"; return false; }
+    return need('}');
+  }
+};
+
+}  // namespace
+
+std::string triple_to_text(const ListTriple &t, bool aggregate_names) {
+  std::string o = "{'N': ";
+  put_number(o, t.N, false);
+  auto dense = [&](const char *name, const std::vector<double> &v) {
+    o += ", '"; o += name; o += "': [";
+    for (size_t i = 0; i < v.size(); i++) { if (i) o += ", "; put_number(o, v[i], true); }
+    o += "]";
+  };
+  dense(aggregate_names ? "lin_agg" : "lin_num", t.lin);
+  dense(aggregate_names ? "quad_agg" : "quad_num", t.quad);
+  auto kv = [&](const char *name, const std::vector<std::vector<KeyVal>> &lists) {
+    o += ", '"; o += name; o += "': [";
+    for (size_t l = 0; l < lists.size(); l++) {
+      o += l ? ", [" : "[";
+      for (size_t e = 0; e < lists[l].size(); e++) {
+        o += e ? ", {'key': " : "{'key': ";
+        put_number(o, lists[l][e].key, false);
+        o += ", 'value': ";
+        put_number(o, lists[l][e].val, true);
+        o += "}";
+      }
+      o += "]";
+    }
+    o += "]";
+  };
+  kv("lin_cat", t.lin_cat);
+  if (!t.kind) {
+    kv("quad_num_cat", t.num_cat);
+    o += ", 'quad_cat': [";
+    for (size_t l = 0; l < t.cat_cat.size(); l++) {
+      o += l ? ", [" : "[";
+      for (size_t e = 0; e < t.cat_cat[l].size(); e++) {
+        o += e ? ", {'key1': " : "{'key1': ";
+        put_number(o, t.cat_cat[l][e].k1, false);
+        o += ", 'key2': ";
+        put_number(o, t.cat_cat[l][e].k2, false);
+        o += ", 'value': ";
+        put_number(o, t.cat_cat[l][e].val, true);
+        o += "}";
+      }
+      o += "]";
+    }
+    o += "]";
+  }
+  o += "}";
+  return o;
+}
+
+bool triple_from_text(const char *text, size_t len, ListTriple &t, std::string &err) {
+  TextCursor c{text, text + len, &err};
+  t = ListTriple();
+  bool have_N = false, have_lin = false, have_quad = false, have_lc = false, have_nc = false, have_cc = false;
+  if (!c.need('{')) return false;
+  do {
+    std::string nm;
+    if (!c.name(nm) || !c.need(':')) return false;
+    if (nm == "N") { if (!c.number(t.N)) return false; have_N = true; }
+    else if (nm == "lin_agg" || nm == "lin_num") { if (!c.numbers(t.lin)) return false; have_lin = true; }
+    else if (nm == "quad_agg" || nm == "quad_num") { if (!c.numbers(t.quad)) return false; have_quad = true; }
+    else if (nm == "lin_cat" || nm == "quad_num_cat") {
+      auto &dst = nm == "lin_cat" ? t.lin_cat : t.num_cat;
+      (nm == "lin_cat" ? have_lc : have_nc) = true;
+      if (!c.need('[')) return false;
+      if (!c.eat(']')) {
+        do {
+          dst.emplace_back();
+          if (!c.need('[')) return false;
+          if (c.eat(']')) continue;
+          do {
+            static const char *const names[] = {"key", "value"};
+            double v[2];
+            if (!c.record(names, 2, v)) return false;
+            dst.back().push_back({(int32_t)v[0], v[1]});
+          } while (c.eat(','));
+          if (!c.need(']')) return false;
+        } while (c.eat(','));
+        if (!c.need(']')) return false;
+      }
+    } else if (nm == "quad_cat") {
+      have_cc = true;
+      if (!c.need('[')) return false;
+      if (!c.eat(']')) {
+        do {
+          t.cat_cat.emplace_back();
+          if (!c.need('[')) return false;
+          if (c.eat(']')) continue;
+          do {
+            static const char *const names[] = {"key1", "key2", "value"};
+            double v[3];
+            if (!c.record(names, 3, v)) return false;
+            t.cat_cat.back().push_back({(int32_t)v[0], (int32_t)v[1], v[2]});
+          } while (c.eat(','));
+          if (!c.need(']')) return false;
+        } while (c.eat(','));
+        if (!c.need(']')) return false;
+      }
+    } else { err = "triple text: unknown field '" + nm + "'"; return false; }
+  } while (c.eat(','));
+  if (!c.need('}')) return false;
+  c.ws();
+  if (c.p != c.end) { err = "triple text: trailing characters"; return false; }
+  if (!have_N || !have_lin || !have_quad || !have_lc) { err = "triple text: N, lin, quad and lin_cat are required"; return false; }
+  if (have_nc != have_cc) { err = "triple text: quad_num_cat and quad_cat come together"; return false; }
+  t.kind = have_cc ? 0 : 1;
+  t.n = (int)t.lin.size();
+  t.m = (int)t.lin_cat.size();
+  const size_t want_quad = t.kind ? (size_t)t.n : tri(t.n);
+  if (t.quad.size() != want_quad) { err = "triple text: quad list length does not fit the lin list"; return false; }
+  if (!t.kind && (t.num_cat.size() != (size_t)t.n * t.m || t.cat_cat.size() != tri(t.m))) {
+    err = "triple text: quad_num_cat / quad_cat list counts do not fit n and m";
+    return false;
+  }
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,6 +30,16 @@ uint64_t blob_len(const double *b, uint64_t cap);
 bool blob_decode(const double *b, uint64_t cap, ListTriple &t, std::string &err);
 void blob_encode(const ListTriple &t, std::vector<double> &out);
 
+// Text form of one triple: DuckDB's STRUCT literal, as Value::ToString() prints the aggregates' result
+// and as the MICE drivers paste it back into SQL (imputation/algorithms/imputation_base.cpp:46,116):
+//   {'N': 5, 'lin_agg': [15.0, 17.0], 'quad_agg': [...], 'lin_cat': [[{'key': 4, 'value': 3.0}, ..], ..],
+//    'quad_num_cat': [[..]], 'quad_cat': [[{'key1': 4, 'key2': 5, 'value': 1.0}, ..], ..]}
+// Numbers are printed with 17 significant digits where fewer do not round-trip, so
+// text -> triple -> text is the identity.  aggregate_names: lin_agg / quad_agg (aggregates) or
+// lin_num / quad_num (scalar functions); the parser takes either, any whitespace, ' or ".
+std::string triple_to_text(const ListTriple &t, bool aggregate_names);
+bool triple_from_text(const char *text, size_t len, ListTriple &t, std::string &err);
+
 // Sparse accumulator (wide: double sums, exact integer counts up to 2^53).
 struct HostTriple {
   int kind = 0, n = 0, m = 0;

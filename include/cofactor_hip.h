@@ -226,6 +226,18 @@ cofactor_status cofactor_triple_sub(const double *a, uint64_t a_len, const doubl
  * every list header against it before reading. */
 uint64_t cofactor_blob_len(const double *blob, uint64_t cap);
 
+/* Text round trip.  The reference's MICE drivers carry a triple from the aggregate
+ * to the trainer as TEXT: Value::ToString() of the result, pasted into the next SQL statement and
+ * cast back (imputation/algorithms/imputation_base.cpp:46-49,116).  to_text writes DuckDB's STRUCT
+ * literal ({'N': 5, 'lin_agg': [15.0, ..], 'lin_cat': [[{'key': 4, 'value': 3.0}, ..], ..], ..}) with
+ * the shortest digits that read back as the same value; from_text parses it (either field-name
+ * flavour, any whitespace).  blob -> text -> blob is the identity.  Two-call protocol; `needed`
+ * counts bytes including the terminating NUL for to_text, doubles for from_text. */
+cofactor_status cofactor_triple_to_text(const double *blob, uint64_t blob_len, int32_t aggregate_names,
+                                        char *out, uint64_t cap, uint64_t *needed);
+cofactor_status cofactor_triple_from_text(const char *text, uint64_t text_len, double *out,
+                                          uint64_t cap, uint64_t *needed);
+
 /* ---- batched ring ops on the GPU (the factorised-join pipeline) ----------------
  *
  *   SELECT sum_triple(multiply_triple(A, B)) FROM

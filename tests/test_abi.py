@@ -169,3 +169,39 @@ def test_multiply_matches_oracle_on_random_triples():
             np.testing.assert_array_equal(cofactor_hip.multiply(A, B), orc.multiply(A, B, orc.FAITHFUL))
             if (n1, m1) == (n2, m2):
                 np.testing.assert_array_equal(cofactor_hip.add(A, B), orc.add(A, B, orc.FAITHFUL))
+
+
+def test_triple_text_round_trip(goldens):
+    """N4: the triple as DuckDB's STRUCT literal text (imputation_base.cpp:46-49,116) and back.  Every
+    reference literal: blob -> text -> blob is the identity; the text parses when written the way
+    Python / DuckDB print it (repr of the golden dict); floats that need 17 digits keep them."""
+    from triple_fmt import dict_to_blob
+    count = 0
+    for fname, doc in goldens.items():
+        agg_names = "sum" in fname
+        for t in doc["tests"]:
+            for e in t["expected"]:
+                blob = dict_to_blob(e["value"])
+                text = cofactor_hip.to_text(blob, aggregate_names=agg_names)
+                assert ("'lin_agg'" in text) == agg_names
+                np.testing.assert_array_equal(cofactor_hip.from_text(text), blob)
+                np.testing.assert_array_equal(cofactor_hip.from_text(repr(e["value"])), blob)
+                count += 1
+    assert count == 60
+    rng = np.random.default_rng(3)
+    from oracle import oracle as orc
+    num = [rng.normal(size=500).astype(np.float32) * 1e-3 for _ in range(3)]
+    cat = [rng.integers(-2_000_000_000, 2_000_000_000, 500).astype(np.int32) for _ in range(2)]
+    for nb in (False, True):
+        blob = orc.State(orc.WIDE).update(num, cat, nb=nb).finalize()      # doubles that are no floats
+        text = cofactor_hip.to_text(blob)
+        np.testing.assert_array_equal(cofactor_hip.from_text(text), blob)
+        assert cofactor_hip.to_text(cofactor_hip.from_text(text)) == text
+    nonfinite = np.array([0.0, 1, 0, 2, np.inf, -np.inf if False else np.nan])
+    back = cofactor_hip.from_text(cofactor_hip.to_text(nonfinite))
+    assert np.isinf(back[4]) and np.isnan(back[5])
+    for bad in ("", "{", "{'N': 1}", "{'N': 1, 'lin_agg': [1.0], 'quad_agg': [1.0, 2.0], 'lin_cat': []}",
+                "{'N': 1, 'lin_agg': [], 'quad_agg': [], 'lin_cat': [], 'quad_cat': []}", "{'N': x}"):
+        with pytest.raises(cofactor_hip.CofactorError) as e:
+            cofactor_hip.from_text(bad)
+        assert e.value.status == cofactor_hip.ERR_INVALID
