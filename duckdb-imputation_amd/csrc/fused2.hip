@@ -122,7 +122,7 @@ __device__ __forceinline__ void smfma(f32x4 &acc, u32x4 a, u32x4 b) {
 // two rows.  The wait states at the end let the MFMA that follows read the last v_perm's result.
 __device__ __forceinline__ u32x4 onehot_bf16(unsigned w0, unsigned w1) {
   u32x4 r;
-  asm("v_perm_b32 %0, 0, %4, %6\n\tv_perm_b32 %1, 0, %4, %7\n\tv_perm_b32 %2, 0, %5, %6\n\tv_perm_b32 %3, 0, %5, %7\n\ts_nop 1"
+  asm("v_perm_b32 %0, 0, %4, %6\n\tv_perm_b32 %1, 0, %4, %7\n\tv_perm_b32 %2, 0, %5, %6\n\tv_perm_b32 %3, 0, %5, %7\n\ts_nop 2"
       : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
       : "v"(w0), "v"(w1), "s"(0x010C000Cu), "s"(0x030C020Cu));
   return r;
@@ -133,6 +133,18 @@ __device__ __forceinline__ unsigned xad(unsigned a, unsigned b, unsigned c) {   
   unsigned r;
   asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
   return r;
+}
+template <int M>
+__device__ __forceinline__ void settle_operands(i32x4 (&oh)[M]) {
+  static_assert(M == 2 || M == 4 || M == 6 || M == 8 || M == 10, "M is even, <= 10");
+  if constexpr (M == 2) asm volatile("s_nop 3" : "+v"(oh[0]), "+v"(oh[1]));
+  if constexpr (M == 4) asm volatile("s_nop 3" : "+v"(oh[0]), "+v"(oh[1]), "+v"(oh[2]), "+v"(oh[3]));
+  if constexpr (M == 6) asm volatile("s_nop 3" : "+v"(oh[0]), "+v"(oh[1]), "+v"(oh[2]), "+v"(oh[3]), "+v"(oh[4]), "+v"(oh[5]));
+  if constexpr (M == 8)
+    asm volatile("s_nop 3" : "+v"(oh[0]), "+v"(oh[1]), "+v"(oh[2]), "+v"(oh[3]), "+v"(oh[4]), "+v"(oh[5]), "+v"(oh[6]), "+v"(oh[7]));
+  if constexpr (M == 10)
+    asm volatile("s_nop 3" : "+v"(oh[0]), "+v"(oh[1]), "+v"(oh[2]), "+v"(oh[3]), "+v"(oh[4]), "+v"(oh[5]), "+v"(oh[6]), "+v"(oh[7]),
+                 "+v"(oh[8]), "+v"(oh[9]));
 }
 __device__ __forceinline__ void pmfma(i32x4 &acc, i32x4 a, i32x4 b) {
   asm("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
@@ -450,8 +462,9 @@ __global__ __launch_bounds__(F2_THREADS, 1) void fused2_kernel(NumCols num, CatC
       oh[c][2] = (int)(xad(cb.z, ixor, 0x21212121u) & 0x40404040u);
       oh[c][3] = (int)(xad(cb.w, ixor, 0x21212121u) & 0x40404040u);
     }
-    // (an asm MFMA must not read a register the VALU instruction right before it wrote)
-    asm volatile("s_nop 1" : "+v"(oh[M - 1]));
+    // (an asm MFMA must not read a register the VALU instruction right before it wrote: every
+    // one-hot register is an operand of this statement, so all of them are complete before it)
+    settle_operands<M>(oh);
     if (PAIRS) {
       int q = 0;
 #pragma unroll
