@@ -78,22 +78,44 @@ __global__ __launch_bounds__(256) void lift_kernel(NumCols num, CatCols cat, int
 }
 
 // ---- sum_triple: dense children -------------------------------------------------------------------
-// acc[0] += sum N, acc[1 + k] += sum lin[.][k], acc[1 + n + q] += sum quad[.][q].  A block walks a
-// chunk of rows, thread k owns column k (a row's D = 1 + n + T values are contiguous: coalesced).
-__global__ __launch_bounds__(256) void tvec_dense_kernel(cofactor_tvec v, int T, double *__restrict__ acc) {
-  const int n = v.n, D = 1 + n + T, k = threadIdx.x;
-  if (k >= D) return;
-  const uint64_t per = (v.count + gridDim.x - 1) / gridDim.x;
-  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = min(v.count, lo + per);
-  double s = 0;
-  for (uint64_t i = lo; i < hi; i++) {
-    float x;
-    if (k == 0) x = (float)v.N[i];
-    else if (k <= n) x = v.lin[v.lin_e[2 * i] + (k - 1)];
-    else x = v.quad[v.quad_e[2 * i] + (k - 1 - n)];
-    s += (double)x;
+// acc[0] += sum N, acc[1 + k] += sum lin[.][k], acc[1 + n + q] += sum quad[.][q].
+// One child array per launch (width W values per row, row i at child[entries[2 i] ..]): thread t of
+// a block owns column t % W of the rows t / W, t / W + RPB, .. of the block's chunk, so that a
+// block iteration reads RPB = 256 / W whole rows = one contiguous stretch (coalesced), four
+// iterations in flight; the per-thread sums meet in LDS.
+__global__ __launch_bounds__(256) void tvec_dense_kernel(const float *__restrict__ child, const uint64_t *__restrict__ entries,
+                                                         const int32_t *__restrict__ Ncol, uint64_t count, int W,
+                                                         double *__restrict__ acc) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  const int RPB = 256 / W;                            // rows per block iteration (W <= 256)
+  const int k = tid % W, r = tid / W;
+  const uint64_t per = (count + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per, hi = min(count, lo + per);
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (r < RPB) {
+    uint64_t i = lo + r;
+    if (Ncol) {                                       // the INTEGER column N (W = 1)
+      for (; i + 3 * (uint64_t)RPB < hi; i += 4 * (uint64_t)RPB) {
+        s0 += (double)Ncol[i]; s1 += (double)Ncol[i + RPB]; s2 += (double)Ncol[i + 2 * RPB]; s3 += (double)Ncol[i + 3 * RPB];
+      }
+      for (; i < hi; i += RPB) s0 += (double)Ncol[i];
+    } else {
+      for (; i + 3 * (uint64_t)RPB < hi; i += 4 * (uint64_t)RPB) {
+        const float a = child[entries[2 * i] + k], b = child[entries[2 * (i + RPB)] + k];
+        const float c = child[entries[2 * (i + 2 * RPB)] + k], d = child[entries[2 * (i + 3 * RPB)] + k];
+        s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+      }
+      for (; i < hi; i += RPB) s0 += (double)child[entries[2 * i] + k];
+    }
   }
-  if (lo < hi) unsafeAtomicAdd(&acc[k], s);
+  red[tid] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (tid < W) {
+    double v = 0;
+    for (int rr = 0; rr < RPB; rr++) v += red[rr * W + tid];
+    if (lo < hi) unsafeAtomicAdd(&acc[tid], v);
+  }
 }
 
 // acc image of the aggregate (gram.hip layout) += the reduced dense vector; kept += N
@@ -113,8 +135,19 @@ __global__ void tvec_dense_apply_kernel(const double *__restrict__ red, int n, i
 // ---- sum_triple: key lists --------------------------------------------------------------------------
 // pass 0: every key of every lin_cat sub-list into its column's dictionary
 // pass 1: lin_cat values -> cnt, quad_num_cat values -> s, quad_cat values -> p (codes via the dictionaries)
+// LDS_TABLES (pass 1 only): the three tables as doubles in LDS, private to the workgroup, added to
+// the aggregate's tables at the end (lifted rows hammer a handful of cells: global atomics on
+// them serialise).
+template <bool LDS_TABLES>
 __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayout L, CatDevice D, int pass) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double *l_t = reinterpret_cast<double *>(lds_raw);   // [cnt | s | p]
   const int n = v.n, m = v.m;
+  const int cells = L.n_cnt + L.n_s + L.n_p;
+  if (LDS_TABLES) {
+    for (int i = threadIdx.x; i < cells; i += 256) l_t[i] = 0.0;
+    __syncthreads();
+  }
   const int Tm = v.kind ? 0 : tri_i(m), nm = v.kind ? 0 : n * m;
   const uint64_t per_row = (uint64_t)m + (pass ? nm + Tm : 0);
   const uint64_t total = v.count * per_row;
@@ -129,7 +162,8 @@ __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayo
         else {
           const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], v.lc_key[e]);
           if (code < 0 || code >= L.kc[c]) { D.flags[1] = 1; continue; }
-          atomicAdd(&D.cnt[L.cnt_off[c] + code], (unsigned long long)(v.lc_val[e] + 0.5f));
+          if (LDS_TABLES) unsafeAtomicAdd(&l_t[L.cnt_off[c] + code], (double)v.lc_val[e]);
+          else atomicAdd(&D.cnt[L.cnt_off[c] + code], (unsigned long long)(v.lc_val[e] + 0.5f));
         }
       }
       continue;
@@ -141,7 +175,8 @@ __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayo
       for (uint64_t e = off; e < off + len; e++) {
         const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], v.nc_key[e]);
         if (code < 0 || code >= L.kc[c]) { D.flags[1] = 1; continue; }
-        unsafeAtomicAdd(&D.s[L.s_off[c] + (long long)code * n + k], (double)v.nc_val[e]);
+        if (LDS_TABLES) unsafeAtomicAdd(&l_t[L.n_cnt + L.s_off[c] + code * n + k], (double)v.nc_val[e]);
+        else unsafeAtomicAdd(&D.s[L.s_off[c] + (long long)code * n + k], (double)v.nc_val[e]);
       }
       continue;
     }
@@ -154,8 +189,19 @@ __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayo
         const int k1 = cat_lookup_code(D.ht_slot + L.ht_off[c1], D.ht_code + L.ht_off[c1], L.ht_cap[c1], v.cc_key1[e]);
         const int k2 = cat_lookup_code(D.ht_slot + L.ht_off[c2], D.ht_code + L.ht_off[c2], L.ht_cap[c2], v.cc_key2[e]);
         if (k1 < 0 || k2 < 0 || k1 >= L.kc[c1] || k2 >= L.kc[c2]) { D.flags[1] = 1; continue; }
-        atomicAdd(&D.p[L.p_off[s] + (long long)k1 * L.kc[c2] + k2], (unsigned long long)(v.cc_val[e] + 0.5f));
+        if (LDS_TABLES) unsafeAtomicAdd(&l_t[L.n_cnt + L.n_s + L.p_off[s] + k1 * L.kc[c2] + k2], (double)v.cc_val[e]);
+        else atomicAdd(&D.p[L.p_off[s] + (long long)k1 * L.kc[c2] + k2], (unsigned long long)(v.cc_val[e] + 0.5f));
       }
+    }
+  }
+  if (LDS_TABLES) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += 256) {
+      const double t = l_t[i];
+      if (t == 0.0) continue;
+      if (i < L.n_cnt) atomicAdd(&D.cnt[i], (unsigned long long)(t + 0.5));
+      else if (i < L.n_cnt + L.n_s) unsafeAtomicAdd(&D.s[i - L.n_cnt], t);
+      else atomicAdd(&D.p[i - L.n_cnt - L.n_s], (unsigned long long)(t + 0.5));
     }
   }
 }
@@ -501,8 +547,15 @@ hipError_t launch_tvec_dense(const cofactor_tvec &v, double *red, double *acc, u
   const int T = v.kind ? v.n : tri_i(v.n);
   hipError_t e = hipMemsetAsync(red, 0, sizeof(double) * 256, stream);
   if (e != hipSuccess) return e;
-  const uint64_t want = (v.count + 63) / 64;
-  hipLaunchKernelGGL(tvec_dense_kernel, dim3((unsigned)std::min<uint64_t>(want, (uint64_t)grid)), dim3(256), 0, stream, v, T, red);
+  const unsigned blocks = (unsigned)std::min<uint64_t>((v.count + 1023) / 1024, (uint64_t)grid);
+  hipLaunchKernelGGL(tvec_dense_kernel, dim3(blocks), dim3(256), 0, stream, (const float *)nullptr, (const uint64_t *)nullptr,
+                     v.N, v.count, 1, red);
+  if (v.n > 0) {
+    hipLaunchKernelGGL(tvec_dense_kernel, dim3(blocks), dim3(256), 0, stream, v.lin, v.lin_e, (const int32_t *)nullptr, v.count,
+                       v.n, red + 1);
+    hipLaunchKernelGGL(tvec_dense_kernel, dim3(blocks), dim3(256), 0, stream, v.quad, v.quad_e, (const int32_t *)nullptr, v.count,
+                       T, red + 1 + v.n);
+  }
   hipLaunchKernelGGL(tvec_dense_apply_kernel, dim3(1), dim3(256), 0, stream, red, v.n, v.kind, acc, kept);
   return hipGetLastError();
 }
@@ -511,7 +564,13 @@ hipError_t launch_tvec_keys(const cofactor_tvec &v, const CatLayout &L, const Ca
   if (v.count == 0 || v.m == 0) return hipSuccess;
   const int Tm = v.kind ? 0 : tri_i(v.m), nm = v.kind ? 0 : v.n * v.m;
   const uint64_t total = v.count * ((uint64_t)v.m + (pass ? nm + Tm : 0));
-  hipLaunchKernelGGL(tvec_keys_kernel, dim3(grid_for(total)), dim3(256), 0, stream, v, L, D, pass);
+  const size_t lds = (size_t)(L.n_cnt + L.n_s + L.n_p) * 8;
+  if (pass == 1 && lds <= 48 * 1024) {
+    const int grid = (int)std::min<uint64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL((tvec_keys_kernel<true>), dim3(grid), dim3(256), lds, stream, v, L, D, pass);
+  } else {
+    hipLaunchKernelGGL((tvec_keys_kernel<false>), dim3(grid_for(total)), dim3(256), 0, stream, v, L, D, pass);
+  }
   return hipGetLastError();
 }
 
