@@ -10,6 +10,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "device.hpp"
@@ -583,12 +585,24 @@ cofactor_status stage_flush(cofactor_agg *a) {
   return COFACTOR_OK;
 }
 
+// What finalize's fast path needs to write the pair lists straight into the blob: the device
+// pair tables as they are (code-indexed), the live codes of every column in ascending key order
+// and their keys.
+struct PairSource {
+  CatLayout L;
+  std::vector<unsigned long long> p;
+  unsigned long long *p_pinned = nullptr;        // (large tables: pinned staging instead of p)
+  std::vector<std::vector<int>> order;
+  std::vector<std::vector<int32_t>> key_of;
+  const unsigned long long *cells() const { return p_pinned ? p_pinned : p.data(); }
+  ~PairSource() { if (p_pinned) (void)hipHostFree(p_pinned); }
+};
+
 // Device tables + host accumulator -> one HostTriple (synchronises).
-// pair_lists (optional): the device pair tables are written there as sorted (key1, key2, count)
-// lists, one per column pair, instead of into out.pair — finalize's fast path for states whose
-// host side holds no keys (no map node per entry: a 1000-key column pair has 1e6 of them).
-cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = false,
-                         std::vector<std::vector<PairVal>> *pair_lists = nullptr) {
+// pair_src (optional): the device pair tables are handed back raw instead of going into out.pair
+// — for states whose host side holds no keys (no map node per entry: a 1000-key column pair has
+// 1e6 of them).
+cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = false, PairSource *pair_src = nullptr) {
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   cofactor_status s = stage_flush(a);
@@ -617,14 +631,26 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
   }
   if (!dense_only && a->m > 0 && a->cat_ready && a->dev_dirty) {
     const CatLayout &L = a->L;
-    std::vector<unsigned long long> slot(L.n_slots), cnt(L.n_cnt), p(std::max(1, L.n_p));
+    std::vector<unsigned long long> slot(L.n_slots), cnt(L.n_cnt), p_local;
     std::vector<int32_t> code(L.n_slots);
     std::vector<double> sums(std::max(1, L.n_s));
+    unsigned long long *p_dst = nullptr;
+    if (L.n_p) {
+      const size_t bytes = sizeof(unsigned long long) * (size_t)L.n_p;
+      if (pair_src && bytes >= ((size_t)32 << 20)) {           // big: straight into pinned memory
+        HIP_TRY(hipHostMalloc((void **)&pair_src->p_pinned, bytes, hipHostMallocDefault));
+        p_dst = pair_src->p_pinned;
+      } else {
+        std::vector<unsigned long long> &pv = pair_src ? pair_src->p : p_local;
+        pv.resize(L.n_p);
+        p_dst = pv.data();
+      }
+    }
     HIP_TRY(hipMemcpyAsync(slot.data(), a->D.ht_slot, sizeof(unsigned long long) * L.n_slots, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(code.data(), a->D.ht_code, sizeof(int32_t) * L.n_slots, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(cnt.data(), a->D.cnt, sizeof(unsigned long long) * L.n_cnt, hipMemcpyDeviceToHost, st));
     if (L.n_s) HIP_TRY(hipMemcpyAsync(sums.data(), a->D.s, sizeof(double) * L.n_s, hipMemcpyDeviceToHost, st));
-    if (L.n_p) HIP_TRY(hipMemcpyAsync(p.data(), a->D.p, sizeof(unsigned long long) * L.n_p, hipMemcpyDeviceToHost, st));
+    if (L.n_p) HIP_TRY(hipMemcpyAsync(p_dst, a->D.p, sizeof(unsigned long long) * L.n_p, hipMemcpyDeviceToHost, st));
     int32_t flags[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(flags, a->D.flags, sizeof(flags), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -659,19 +685,23 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
           if (live[c][k]) order[c].push_back(k);
         std::sort(order[c].begin(), order[c].end(), [&](int x, int y) { return key_of[c][x] < key_of[c][y]; });
       }
-      int q = 0;
-      if (pair_lists) pair_lists->assign(tri(a->m), {});
-      for (int c1 = 0; c1 < a->m; c1++)
-        for (int c2 = c1; c2 < a->m; c2++, q++) {
-          auto &tab = out.pair[q];
-          for (int k1 : order[c1])
-            for (int k2 : order[c2]) {
-              const unsigned long long v = p[L.p_off[q] + (size_t)k1 * L.kc[c2] + k2];
-              if (!v) continue;
-              if (pair_lists) (*pair_lists)[q].push_back({key_of[c1][k1], key_of[c2][k2], (double)v});
-              else tab.emplace_hint(tab.end(), std::make_pair(key_of[c1][k1], key_of[c2][k2]), (double)v);
-            }
-        }
+      if (pair_src) {
+        pair_src->L = L;
+        pair_src->order = std::move(order);
+        pair_src->key_of = std::move(key_of);
+      } else {
+        int q = 0;
+        for (int c1 = 0; c1 < a->m; c1++)
+          for (int c2 = c1; c2 < a->m; c2++, q++) {
+            auto &tab = out.pair[q];
+            for (int k1 : order[c1])
+              for (int k2 : order[c2]) {
+                const unsigned long long v = p_dst[L.p_off[q] + (size_t)k1 * L.kc[c2] + k2];
+                if (!v) continue;
+                tab.emplace_hint(tab.end(), std::make_pair(key_of[c1][k1], key_of[c2][k2]), (double)v);
+              }
+          }
+      }
     }
   }
   if (dense_only) {
@@ -685,12 +715,119 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
   return COFACTOR_OK;
 }
 
-cofactor_status emit_blob(const std::vector<double> &blob, double *out, uint64_t cap, uint64_t *needed) {
-  if (needed) *needed = blob.size();
+// Runs fn(task) for task = 0..tasks-1 on up to 32 threads (dynamic hand-out); on the calling
+// thread alone when the job is small.
+template <class F>
+void parallel_tasks(size_t tasks, bool big, F &&fn) {
+  unsigned nt = big ? std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  if (nt > tasks) nt = (unsigned)std::max<size_t>(1, tasks);
+  if (nt <= 1) {
+    for (size_t t = 0; t < tasks; t++) fn(t);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (size_t t = next.fetch_add(1); t < tasks; t = next.fetch_add(1)) fn(t);
+  };
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (unsigned i = 1; i < nt; i++) th.emplace_back(worker);
+  worker();
+  for (auto &t : th) t.join();
+}
+
+// The quad_cat part of the blob from the raw pair tables: per column pair [count, (key1, key2,
+// value)...] in ascending (key1, key2) order.  Two sweeps over blocks of table rows (count
+// non-zero cells, then write), spread over threads: a 10-column table with 1000 keys per column
+// has 5.5e7 non-zero cells.
+void encode_pair_lists(const PairSource &src, int m, BlobVec &blob) {
+  const CatLayout &L = src.L;
+  const unsigned long long *p = src.cells();
+  constexpr int RB = 64;                                      // table rows per task
+  struct Task { int q, c1, c2, r0, r1; };
+  std::vector<Task> tasks;
+  std::vector<size_t> first_task(tri(m) + 1, 0);
+  {
+    int q = 0;
+    for (int c1 = 0; c1 < m; c1++)
+      for (int c2 = c1; c2 < m; c2++, q++) {
+        first_task[q] = tasks.size();
+        const int rows1 = (int)src.order[c1].size();
+        for (int r = 0; r < rows1; r += RB) tasks.push_back({q, c1, c2, r, std::min(rows1, r + RB)});
+      }
+    first_task[q] = tasks.size();
+  }
+  size_t cells = 0;
+  for (auto const &t : tasks) cells += (size_t)(t.r1 - t.r0) * src.order[t.c2].size();
+  const bool big = cells >= ((size_t)1 << 21);
+  std::vector<size_t> found(tasks.size() + 1, 0);
+  parallel_tasks(tasks.size(), big, [&](size_t ti) {
+    const Task &t = tasks[ti];
+    const auto &o1 = src.order[t.c1];
+    const auto &o2 = src.order[t.c2];
+    size_t nz = 0;
+    for (int r = t.r0; r < t.r1; r++) {
+      const unsigned long long *row = p + L.p_off[t.q] + (size_t)o1[r] * L.kc[t.c2];
+      for (int k2 : o2) nz += row[k2] != 0ull;
+    }
+    found[ti] = nz;
+  });
+  // blob offsets: every list is preceded by its length
+  std::vector<size_t> at(tasks.size() + 1, 0);
+  std::vector<size_t> head(tri(m), 0);
+  size_t o = blob.size();
+  for (int q = 0; q < tri(m); q++) {
+    head[q] = o++;
+    for (size_t ti = first_task[q]; ti < first_task[q + 1]; ti++) { at[ti] = o; o += 3 * found[ti]; }
+  }
+  blob.resize(o);                                             // (default-initialised: see BlobVec)
+  for (int q = 0; q < tri(m); q++) {
+    size_t cnt = 0;
+    for (size_t ti = first_task[q]; ti < first_task[q + 1]; ti++) cnt += found[ti];
+    blob[head[q]] = (double)cnt;
+  }
+  double *out = blob.data();
+  parallel_tasks(tasks.size(), big, [&](size_t ti) {
+    const Task &t = tasks[ti];
+    const auto &o1 = src.order[t.c1];
+    const auto &o2 = src.order[t.c2];
+    const auto &k1s = src.key_of[t.c1];
+    const auto &k2s = src.key_of[t.c2];
+    double *w = out + at[ti];
+    for (int r = t.r0; r < t.r1; r++) {
+      const int cd1 = o1[r];
+      const unsigned long long *row = p + L.p_off[t.q] + (size_t)cd1 * L.kc[t.c2];
+      const double key1 = (double)k1s[cd1];
+      for (int k2 : o2) {
+        const unsigned long long v = row[k2];
+        if (!v) continue;
+        w[0] = key1; w[1] = (double)k2s[k2]; w[2] = (double)v;
+        w += 3;
+      }
+    }
+  });
+}
+
+// memcpy of a blob, on several threads when it is hundreds of MB
+void copy_blob(double *dst, const double *src, size_t count) {
+  constexpr size_t CH = (size_t)1 << 21;                      // 16 MB per task
+  const size_t tasks = (count + CH - 1) / CH;
+  parallel_tasks(tasks, count >= ((size_t)1 << 24), [&](size_t t) {
+    const size_t lo = t * CH, hi = std::min(count, lo + CH);
+    std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(double));
+  });
+}
+
+cofactor_status emit_blob(const double *blob, size_t size, double *out, uint64_t cap, uint64_t *needed) {
+  if (needed) *needed = size;
   if (!out) return COFACTOR_OK;
-  if (cap < blob.size()) return fail(COFACTOR_ERR_CAPACITY, "output buffer too small");
-  std::memcpy(out, blob.data(), blob.size() * sizeof(double));
+  if (cap < size) return fail(COFACTOR_ERR_CAPACITY, "output buffer too small");
+  copy_blob(out, blob, size);
   return COFACTOR_OK;
+}
+
+cofactor_status emit_blob(const std::vector<double> &blob, double *out, uint64_t cap, uint64_t *needed) {
+  return emit_blob(blob.data(), blob.size(), out, cap, needed);
 }
 
 }  // namespace detail
@@ -1020,29 +1157,22 @@ cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap
     bool host_has_keys = false;       // keys merged in on the host (combine, lifted triples)
     for (auto const &c : a->host.col) host_has_keys = host_has_keys || !c.empty();
     for (auto const &t : a->host.pair) host_has_keys = host_has_keys || !t.empty();
-    std::vector<std::vector<PairVal>> pairs;
+    PairSource pairs;
     const bool direct = a->kind == COFACTOR_TRIPLE && a->m > 0 && !host_has_keys;
     cofactor_status s = snapshot(a, snap, false, direct ? &pairs : nullptr);
     if (s != COFACTOR_OK) return s;
-    a->blob_cache.clear();
-    if (direct) {
-      pairs.resize(tri(a->m));
-      size_t extra = 0;
-      for (auto const &l : pairs) extra += 1 + 3 * l.size();
-      snap.encode_without_pairs(a->blob_cache);
-      a->blob_cache.reserve(a->blob_cache.size() + extra);
-      for (auto const &l : pairs) {
-        a->blob_cache.push_back((double)l.size());
-        for (auto const &e : l) {
-          a->blob_cache.push_back(e.k1); a->blob_cache.push_back(e.k2); a->blob_cache.push_back(e.val);
-        }
-      }
+    std::vector<double> head;
+    if (direct && (int)pairs.order.size() == a->m) {
+      snap.encode_without_pairs(head);
+      a->blob_cache.assign(head.begin(), head.end());
+      encode_pair_lists(pairs, a->m, a->blob_cache);
     } else {
-      snap.encode(a->blob_cache);
+      snap.encode(head);
+      a->blob_cache.assign(head.begin(), head.end());
     }
     a->blob_cache_valid = true;
   }
-  return emit_blob(a->blob_cache, out, cap, needed);
+  return emit_blob(a->blob_cache.data(), a->blob_cache.size(), out, cap, needed);
 }
 
 uint64_t cofactor_dense_len(int n_num, cofactor_kind kind) {

@@ -12,6 +12,18 @@
 #include "device.hpp"
 #include "triple.hpp"
 
+// std::vector whose resize() leaves new doubles uninitialised (a blob of 1e8 doubles is written
+// by several threads right after: value-initialising it first would touch every page twice)
+template <class T>
+struct default_init_alloc : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_alloc<U>; };
+  template <class U, class... A> void construct(U *ptr, A &&...args) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)ptr) U;
+    else ::new ((void *)ptr) U(std::forward<A>(args)...);
+  }
+};
+using BlobVec = std::vector<double, default_init_alloc<double>>;
+
 struct cofactor_ctx {
   // Aggregates of one context share its stream and scratch buffers (partials, pair slabs, skip
   // list): every entry point that enqueues device work holds this lock for its whole sequence.
@@ -59,7 +71,7 @@ struct cofactor_agg {
   bool cat_check_pending = false;
   int32_t nkeys_host[COFACTOR_MAX_CAT] = {0};
   // finalize's two-call protocol: the blob of the size query is kept for the fill call
-  std::vector<double> blob_cache;
+  BlobVec blob_cache;
   bool blob_cache_valid = false;
   cofactor::CatLayout L{};
   cofactor::CatDevice D{};
@@ -111,6 +123,7 @@ cofactor_status stage_flush(cofactor_agg *a);
 cofactor_status cat_dictionaries_with(cofactor_agg *a, const std::function<hipError_t()> &insert);
 cofactor_status cat_dictionaries(cofactor_agg *a, const CatCols &cat, uint64_t rows);
 cofactor_status emit_blob(const std::vector<double> &blob, double *out, uint64_t cap, uint64_t *needed);
+cofactor_status emit_blob(const double *blob, size_t size, double *out, uint64_t cap, uint64_t *needed);
 
 }  // namespace detail
 }  // namespace cofactor

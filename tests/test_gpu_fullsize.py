@@ -82,6 +82,48 @@ def test_10_10_100M_rows_counts_exact(ctx):
             q += 1
 
 
+def test_10_10_thousand_keys_per_column_exact(ctx):
+    """SURVEY §8(d)'s stress input: 10 float + 10 int32 columns with K = 1000 keys each, 4e7 rows
+    (pair tables of 1e6 cells each, all 5.5e7 cells non-empty: the generic path's HBM pair
+    launches and finalize's threaded list encoding).  Key counts, per-key sums of 0..7-valued
+    columns and every pair table against torch.bincount, exactly; keys are spread out and
+    negative so that codes differ from keys."""
+    import torch
+    from triple_fmt import blob_sections
+    rows, n, m, K = 40_000_000, 10, 10, 1000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    num = [torch.randint(0, 8, (rows,), generator=g, device="cuda", dtype=torch.int32).float() for _ in range(n)]
+    code = [torch.randint(0, K, (rows,), generator=g, device="cuda", dtype=torch.int32) for _ in range(m)]
+    cat = [(c * 37 - 5000).contiguous() for c in code]
+    torch.cuda.synchronize()
+    agg = ctx.aggregate(n, m)
+    agg.update_device(num, cat)
+    blob = agg.finalize()
+    agg.close()
+    head, lin_cat, num_cat, cat_cat = blob_sections(blob)
+    assert head["N"] == rows
+    keys = np.arange(K, dtype=np.float64) * 37 - 5000
+    for c in range(m):
+        cnt = torch.bincount(code[c], minlength=K).cpu().numpy().astype(np.float64)
+        assert np.array_equal(lin_cat[c][:, 0], keys)
+        assert np.array_equal(lin_cat[c][:, 1], cnt)
+    for (k, c) in [(0, 0), (3, 7), (9, 9), (5, 2)]:
+        s = torch.bincount(code[c], weights=num[k].double(), minlength=K).cpu().numpy()
+        assert np.array_equal(num_cat[k * m + c][:, 0], keys)
+        assert np.array_equal(num_cat[k * m + c][:, 1], s)
+    q = 0
+    for c1 in range(m):
+        for c2 in range(c1, m):
+            pc = torch.bincount(code[c1].long() * K + code[c2].long(), minlength=K * K).cpu().numpy()
+            nz = np.flatnonzero(pc)
+            got = cat_cat[q]
+            assert got.shape[0] == nz.size, (c1, c2)
+            assert np.array_equal(got[:, 0], keys[nz // K]), (c1, c2)
+            assert np.array_equal(got[:, 1], keys[nz % K]), (c1, c2)
+            assert np.array_equal(got[:, 2], pc[nz].astype(np.float64)), (c1, c2)
+            q += 1
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 7, 8, 10, 12, 13, 16])
 def test_narrow_tables_exact_through_the_tile_ring(ctx, n):
     """Narrow tables run gram_kernel with a ring of several tiles per workgroup and several rows

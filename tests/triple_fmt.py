@@ -48,6 +48,35 @@ def blob_to_dict(blob, names="agg"):
     return out
 
 
+def blob_sections(blob):
+    """The same walk without a Python object per entry (blobs with 1e7+ entries): returns
+    (header dict, lin_cat, quad_num_cat, quad_cat) where every list is a numpy view of shape
+    [entries, 2] (key, value) or [entries, 3] (key1, key2, value)."""
+    b = np.asarray(blob, dtype=np.float64)
+    kind, n, m = int(b[0]), int(b[1]), int(b[2])
+    p = 4
+    head = {"kind": kind, "n": n, "m": m, "N": int(b[3]), "lin": b[p:p + n]}
+    p += n
+    qn = n if kind else tri(n)
+    head["quad"] = b[p:p + qn]
+    p += qn
+
+    def lists(count, width):
+        nonlocal p
+        res = []
+        for _ in range(count):
+            ln = int(b[p]); p += 1
+            res.append(b[p:p + width * ln].reshape(ln, width))
+            p += width * ln
+        return res
+
+    lin_cat = lists(m, 2)
+    num_cat = lists(n * m, 2) if kind == 0 else []
+    cat_cat = lists(tri(m), 3) if kind == 0 else []
+    assert p == len(b), (p, len(b))
+    return head, lin_cat, num_cat, cat_cat
+
+
 def dict_to_blob(d, kind=None):
     names = "agg" if "lin_agg" in d else "num"
     if kind is None:
