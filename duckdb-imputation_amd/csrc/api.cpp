@@ -62,9 +62,15 @@ void cat_free(CatDevice &D) {
   D = CatDevice{};
 }
 
+// A pair table with more than this many cells is kept as a sparse list (sparse.hpp); so are the
+// largest remaining ones while the dense total would pass 2^30 cells.  COFACTOR_SPARSE_CELLS
+// overrides the threshold (tests).
+static uint64_t sparse_threshold() { return (uint64_t)env_long("COFACTOR_SPARSE_CELLS", 1l << 26); }
+
 // Fills offsets / totals of L from its n, m, kind, ht_cap[], kc[].  False if a table would
-// overflow the 31-bit indices the kernels use.
-bool cat_finish_layout(CatLayout &L) {
+// overflow the 31-bit indices the kernels use.  allow_sparse: oversized pair tables are marked
+// sparse (no dense cells) instead of failing — the aggregate path only.
+bool cat_finish_layout(CatLayout &L, bool allow_sparse) {
   uint64_t slots = 0, cnt = 0, s = 0, p = 0;
   for (int c = 0; c < L.m; c++) {
     L.ht_off[c] = (int)slots; slots += (uint64_t)L.ht_cap[c];
@@ -72,13 +78,34 @@ bool cat_finish_layout(CatLayout &L) {
     L.s_off[c] = (int)s;      s += (uint64_t)L.kc[c] * (uint64_t)L.n;
     if (slots > (1ull << 30) || cnt > (1ull << 30) || s > (1ull << 30)) return false;
   }
-  int q = 0;
-  for (int c1 = 0; c1 < L.m; c1++)
-    for (int c2 = c1; c2 < L.m; c2++, q++) {
-      L.p_off[q] = (int)p;
-      p += (uint64_t)L.kc[c1] * (uint64_t)L.kc[c2];
-      if (p > (1ull << 30)) return false;
+  for (auto &w : L.sparse_mask) w = 0u;
+  const int npairs = L.m * (L.m + 1) / 2;
+  std::vector<uint64_t> cells(npairs, 0);
+  {
+    int q = 0;
+    for (int c1 = 0; c1 < L.m; c1++)
+      for (int c2 = c1; c2 < L.m; c2++, q++) cells[q] = (uint64_t)L.kc[c1] * (uint64_t)L.kc[c2];
+  }
+  if (L.kind == 0 && allow_sparse) {
+    uint64_t dense = 0;
+    for (int q = 0; q < npairs; q++) {
+      if (cells[q] > sparse_threshold()) L.sparse_mask[q >> 5] |= 1u << (q & 31);
+      else dense += cells[q];
     }
+    while (dense > (1ull << 30)) {                // still too much: the largest dense table goes sparse
+      int big = -1;
+      for (int q = 0; q < npairs; q++)
+        if (!pair_is_sparse(L, q) && (big < 0 || cells[q] > cells[big])) big = q;
+      if (big < 0) break;
+      L.sparse_mask[big >> 5] |= 1u << (big & 31);
+      dense -= cells[big];
+    }
+  }
+  for (int q = 0; q < npairs; q++) {
+    L.p_off[q] = (int)p;
+    if (!pair_is_sparse(L, q)) p += cells[q];
+    if (p > (1ull << 30)) return false;
+  }
   L.n_slots = (int)slots; L.n_cnt = (int)cnt;
   L.n_s = L.kind == 0 ? (int)s : 0;
   L.n_p = L.kind == 0 ? (int)p : 0;
@@ -115,9 +142,35 @@ cofactor_status cat_regrow(cofactor_agg *a, const CatLayout &Lnew) {
   if (s != COFACTOR_OK) return s;
   Dn.nkeys = a->D.nkeys;
   Dn.flags = a->D.flags;
-  HIP_TRY(launch_cat_rehash(a->L, a->D, Lnew, Dn, st));
-  HIP_TRY(launch_cat_relayout(a->L, a->D, Lnew, Dn, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  hipError_t e = launch_cat_rehash(a->L, a->D, Lnew, Dn, st);
+  if (e == hipSuccess) e = launch_cat_relayout(a->L, a->D, Lnew, Dn, st);
+  // a pair table that is dense in the old layout and sparse in the new one moves into its store
+  if (e == hipSuccess && a->kind == COFACTOR_TRIPLE && any_sparse_pair(Lnew)) {
+    const CatLayout &Lo = a->L;
+    int32_t *key_of = nullptr;
+    a->sparse.resize(tri(a->m));
+    int q = 0;
+    for (int c1 = 0; c1 < a->m && e == hipSuccess; c1++)
+      for (int c2 = c1; c2 < a->m && e == hipSuccess; c2++, q++) {
+        if (!pair_is_sparse(Lnew, q) || pair_is_sparse(Lo, q) || !a->dev_dirty) continue;
+        if (!key_of) {
+          e = hipMalloc((void **)&key_of, sizeof(int32_t) * std::max(1, Lo.n_cnt));
+          for (int c = 0; c < a->m && e == hipSuccess; c++)
+            e = launch_key_of_code(a->D.ht_slot + Lo.ht_off[c], a->D.ht_code + Lo.ht_off[c], Lo.ht_cap[c], Lo.kc[c],
+                                   key_of + Lo.cnt_off[c], st);
+        }
+        if (e == hipSuccess)
+          e = sparse_add_dense(a->ctx->sparse_sc, a->sparse[q], a->D.p + Lo.p_off[q], Lo.kc[c1], Lo.kc[c2],
+                               key_of + Lo.cnt_off[c1], key_of + Lo.cnt_off[c2], st);
+      }
+    if (key_of) { (void)hipStreamSynchronize(st); (void)hipFree(key_of); }
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    Dn.nkeys = nullptr; Dn.flags = nullptr;
+    cat_free(Dn);
+    return hip_fail(e, "cat_regrow");
+  }
   CatDevice old = a->D;
   old.nkeys = nullptr; old.flags = nullptr;     // kept
   cat_free(old);
@@ -132,7 +185,7 @@ cofactor_status cat_prepare(cofactor_agg *a) {
   L = CatLayout{};
   L.n = a->n; L.m = a->m; L.kind = a->kind;
   for (int c = 0; c < a->m; c++) { L.ht_cap[c] = 64; L.kc[c] = 16; }
-  if (!cat_finish_layout(L)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical layout overflow");
+  if (!cat_finish_layout(L, true)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical layout overflow");
   cofactor_status s = cat_alloc(L, a->D, true, a->ctx->stream);
   if (s != COFACTOR_OK) return s;
   a->cat_ready = true;
@@ -167,7 +220,7 @@ cofactor_status cat_dictionaries_with(cofactor_agg *a, const std::function<hipEr
       if (Ln.ht_cap[c] >= (1 << 28)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical column has too many distinct keys");
       Ln.ht_cap[c] *= 4;
     }
-    if (!cat_finish_layout(Ln)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical dictionaries too large");
+    if (!cat_finish_layout(Ln, true)) return fail(COFACTOR_ERR_UNSUPPORTED, "categorical dictionaries too large");
     s = cat_regrow(a, Ln);
     if (s != COFACTOR_OK) return s;
   }
@@ -184,10 +237,8 @@ cofactor_status cat_dictionaries_with(cofactor_agg *a, const std::function<hipEr
     while (counters[c] * 2 > Ln.ht_cap[c]) { Ln.ht_cap[c] *= 2; grow = true; }  // load factor <= 1/2
   }
   if (grow) {
-    if (!cat_finish_layout(Ln))
-      return fail(COFACTOR_ERR_UNSUPPORTED,
-                  "categorical cardinalities too high for dense code-indexed pair tables "
-                  "(sparse pair tables are not implemented yet)");
+    if (!cat_finish_layout(Ln, true))
+      return fail(COFACTOR_ERR_UNSUPPORTED, "categorical column has too many distinct keys for its count / sum tables");
     s = cat_regrow(a, Ln);
     if (s != COFACTOR_OK) return s;
   }
@@ -225,6 +276,7 @@ void plan_cat_passes(const CatLayout &L, size_t lds_budget, std::vector<CatPass>
     hbm_needed = true;
   }
   for (int q = 0; q < npairs; q++) {
+    if (pair_is_sparse(L, q)) continue;           // (kept as a sorted list: cat_accumulate's last step)
     const size_t cells = (size_t)L.kc[c1_of[q]] * (size_t)L.kc[c2_of[q]];
     const size_t bytes = cells * 4;
     if (bytes > budget) {                         // too big for LDS on its own
@@ -277,15 +329,39 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
     HIP_TRY(hipEventCreate(&e1));
     ctx->cat_ev.emplace_back(e0, e1);
   }
-  if (passes.size() == 1 && !hbm_needed)           // one launch does it all
-    return launch_cat_accumulate(num, cat, rows, L, a->D, passes[0], true, ctx->cat_grid, st, e0, e1, mask) == hipSuccess
-               ? COFACTOR_OK : hip_fail(hipGetLastError(), "cat_accumulate");
+  // pair tables kept as sorted lists: sort + merge per piece of the batch (sparse.hip)
+  const bool with_sparse = L.kind == 0 && any_sparse_pair(L);
+  auto sparse_step = [&](const CatCols &pc, const uint8_t *pmask, uint64_t prows) -> cofactor_status {
+    if (!with_sparse) return COFACTOR_OK;
+    a->sparse.resize(tri(L.m));
+    int q = 0;
+    for (int c1 = 0; c1 < L.m; c1++)
+      for (int c2 = c1; c2 < L.m; c2++, q++)
+        if (pair_is_sparse(L, q)) {
+          hipError_t e = sparse_add_rows(ctx->sparse_sc, a->sparse[q], pc.p[c1], pc.p[c2], pmask, prows, st);
+          if (e == hipErrorInvalidValue)
+            return fail(COFACTOR_ERR_UNSUPPORTED, "a sparse pair table would pass 2^31 entries");
+          if (e != hipSuccess) return hip_fail(e, "sparse pair table");
+        }
+    return COFACTOR_OK;
+  };
+  const uint64_t piece = 1ull << 27;               // rows per code-cache fill / per sort
+  if (passes.size() == 1 && !hbm_needed) {         // one launch does all dense tables
+    if (launch_cat_accumulate(num, cat, rows, L, a->D, passes[0], true, ctx->cat_grid, st, e0, e1, mask) != hipSuccess)
+      return hip_fail(hipGetLastError(), "cat_accumulate");
+    for (uint64_t off = 0; with_sparse && off < rows; off += piece) {
+      CatCols pc = cat;
+      for (int c = 0; c < L.m; c++) pc.p[c] = cat.p[c] + off;
+      cofactor_status s = sparse_step(pc, mask ? mask + off : nullptr, std::min(piece, rows - off));
+      if (s != COFACTOR_OK) return s;
+    }
+    return COFACTOR_OK;
+  }
   // a column whose own count + sum tables exceed LDS: counts and sums with global atomics (old path)
   const bool do_s = L.kind == 0 && L.n > 0;
   bool sums_fit = true;
   for (int c = 0; c < L.m; c++) sums_fit = sums_fit && cat_sums_lds_bytes(L, 1u << c, do_s) <= ctx->lds_budget;
   if (e0) HIP_TRY(hipEventRecord(e0, st));
-  const uint64_t piece = 1ull << 27;               // rows per code-cache fill
   for (uint64_t off = 0; off < rows; off += piece) {
     const uint64_t prows = std::min(piece, rows - off), stride = (prows + 3) / 4 * 4;
     NumCols pn = num;
@@ -328,9 +404,22 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
         used = 0;
         return e;
       };
+      // (a column with more than 32768 codes does not fit the 16-bit code cache: its dense pair
+      // tables are updated from the raw keys by the one-launch kernel, global atomics)
+      CatPass wide{};
+      bool any_wide = false;
+      wide.dict_lds = hbm.dict_lds;
       int q = 0;
       for (int c1 = 0; c1 < L.m; c1++)
         for (int c2 = c1; c2 < L.m && q < npairs; c2++, q++) {
+          if (pair_is_sparse(L, q)) continue;
+          if (L.kc[c1] > 32768 || L.kc[c2] > 32768) {
+            HIP_TRY(flush());                     // (its cells interrupt the run of LDS tables)
+            wide.pair_mask[q >> 5] |= 1u << (q & 31);
+            wide.col_mask |= (1u << c1) | (1u << c2);
+            any_wide = true;
+            continue;
+          }
           const size_t bytes = (size_t)L.kc[c1] * (size_t)L.kc[c2] * 4;
           if (bytes > ctx->lds_budget) { HIP_TRY(flush()); big.push_back(q); continue; }
           if (used + bytes > ctx->lds_budget) HIP_TRY(flush());
@@ -353,6 +442,10 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
         HIP_TRY(launch_cat_pairs(ctx->code_cache, prows, stride, L, a->D, one, ctx->pair_tmp, ctx->cat_grid, st));
         HIP_TRY(launch_cat_fold_u32(ctx->pair_tmp, (long long)cells, a->D.p + L.p_off[qb], st));
       }
+      if (any_wide)
+        HIP_TRY(launch_cat_accumulate(pn, pc, prows, L, a->D, wide, false, ctx->cat_grid, st, nullptr, nullptr, pmask));
+      s = sparse_step(pc, pmask, prows);
+      if (s != COFACTOR_OK) return s;
     }
   }
   if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -594,6 +687,8 @@ struct PairSource {
   unsigned long long *p_pinned = nullptr;        // (large tables: pinned staging instead of p)
   std::vector<std::vector<int>> order;
   std::vector<std::vector<int32_t>> key_of;
+  // sparse pairs (L.sparse_mask): the store's packed keys and counts, already in list order
+  std::vector<std::vector<unsigned long long>> skeys, scnt;
   const unsigned long long *cells() const { return p_pinned ? p_pinned : p.data(); }
   ~PairSource() { if (p_pinned) (void)hipHostFree(p_pinned); }
 };
@@ -685,15 +780,38 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
           if (live[c][k]) order[c].push_back(k);
         std::sort(order[c].begin(), order[c].end(), [&](int x, int y) { return key_of[c][x] < key_of[c][y]; });
       }
+      // sparse pair tables: sorted lists of packed keys, straight from their stores
+      std::vector<std::vector<unsigned long long>> skeys(tri(a->m)), scnt(tri(a->m));
+      if (any_sparse_pair(L)) {
+        for (int q = 0; q < tri(a->m) && q < (int)a->sparse.size(); q++) {
+          const SparseStore &sp = a->sparse[q];
+          if (!pair_is_sparse(L, q) || sp.len == 0) continue;
+          skeys[q].resize(sp.len);
+          scnt[q].resize(sp.len);
+          HIP_TRY(hipMemcpyAsync(skeys[q].data(), sp.keys, sp.len * 8, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipMemcpyAsync(scnt[q].data(), sp.cnt, sp.len * 8, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+      }
       if (pair_src) {
         pair_src->L = L;
         pair_src->order = std::move(order);
         pair_src->key_of = std::move(key_of);
+        pair_src->skeys = std::move(skeys);
+        pair_src->scnt = std::move(scnt);
       } else {
         int q = 0;
         for (int c1 = 0; c1 < a->m; c1++)
           for (int c2 = c1; c2 < a->m; c2++, q++) {
             auto &tab = out.pair[q];
+            if (pair_is_sparse(L, q)) {
+              for (size_t i = 0; i < skeys[q].size(); i++) {
+                int32_t k1, k2;
+                sparse_unpack(skeys[q][i], k1, k2);
+                tab.emplace_hint(tab.end(), std::make_pair(k1, k2), (double)scnt[q][i]);
+              }
+              continue;
+            }
             for (int k1 : order[c1])
               for (int k2 : order[c2]) {
                 const unsigned long long v = p_dst[L.p_off[q] + (size_t)k1 * L.kc[c2] + k2];
@@ -744,7 +862,8 @@ void encode_pair_lists(const PairSource &src, int m, BlobVec &blob) {
   const CatLayout &L = src.L;
   const unsigned long long *p = src.cells();
   constexpr int RB = 64;                                      // table rows per task
-  struct Task { int q, c1, c2, r0, r1; };
+  constexpr size_t SB = (size_t)1 << 16;                      // entries of a sparse store per task
+  struct Task { int q, c1, c2; long long r0, r1; };
   std::vector<Task> tasks;
   std::vector<size_t> first_task(tri(m) + 1, 0);
   {
@@ -752,21 +871,27 @@ void encode_pair_lists(const PairSource &src, int m, BlobVec &blob) {
     for (int c1 = 0; c1 < m; c1++)
       for (int c2 = c1; c2 < m; c2++, q++) {
         first_task[q] = tasks.size();
+        if (pair_is_sparse(L, q)) {               // entries [r0, r1) of the sorted store
+          const size_t len = q < (int)src.skeys.size() ? src.skeys[q].size() : 0;
+          for (size_t r = 0; r < len; r += SB) tasks.push_back({q, -1, -1, (long long)r, (long long)std::min(len, r + SB)});
+          continue;
+        }
         const int rows1 = (int)src.order[c1].size();
         for (int r = 0; r < rows1; r += RB) tasks.push_back({q, c1, c2, r, std::min(rows1, r + RB)});
       }
     first_task[q] = tasks.size();
   }
   size_t cells = 0;
-  for (auto const &t : tasks) cells += (size_t)(t.r1 - t.r0) * src.order[t.c2].size();
+  for (auto const &t : tasks) cells += t.c1 < 0 ? (size_t)(t.r1 - t.r0) : (size_t)(t.r1 - t.r0) * src.order[t.c2].size();
   const bool big = cells >= ((size_t)1 << 21);
   std::vector<size_t> found(tasks.size() + 1, 0);
   parallel_tasks(tasks.size(), big, [&](size_t ti) {
     const Task &t = tasks[ti];
+    if (t.c1 < 0) { found[ti] = (size_t)(t.r1 - t.r0); return; }
     const auto &o1 = src.order[t.c1];
     const auto &o2 = src.order[t.c2];
     size_t nz = 0;
-    for (int r = t.r0; r < t.r1; r++) {
+    for (long long r = t.r0; r < t.r1; r++) {
       const unsigned long long *row = p + L.p_off[t.q] + (size_t)o1[r] * L.kc[t.c2];
       for (int k2 : o2) nz += row[k2] != 0ull;
     }
@@ -789,12 +914,22 @@ void encode_pair_lists(const PairSource &src, int m, BlobVec &blob) {
   double *out = blob.data();
   parallel_tasks(tasks.size(), big, [&](size_t ti) {
     const Task &t = tasks[ti];
+    double *w = out + at[ti];
+    if (t.c1 < 0) {
+      const auto &ks = src.skeys[t.q];
+      const auto &cs = src.scnt[t.q];
+      for (long long r = t.r0; r < t.r1; r++, w += 3) {
+        int32_t k1, k2;
+        sparse_unpack(ks[(size_t)r], k1, k2);
+        w[0] = (double)k1; w[1] = (double)k2; w[2] = (double)cs[(size_t)r];
+      }
+      return;
+    }
     const auto &o1 = src.order[t.c1];
     const auto &o2 = src.order[t.c2];
     const auto &k1s = src.key_of[t.c1];
     const auto &k2s = src.key_of[t.c2];
-    double *w = out + at[ti];
-    for (int r = t.r0; r < t.r1; r++) {
+    for (long long r = t.r0; r < t.r1; r++) {
       const int cd1 = o1[r];
       const unsigned long long *row = p + L.p_off[t.q] + (size_t)cd1 * L.kc[t.c2];
       const double key1 = (double)k1s[cd1];
@@ -879,6 +1014,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->ring_red);
   (void)hipFree(ctx->code_cache);
   (void)hipFree(ctx->pair_tmp);
+  sparse_scratch_free(ctx->sparse_sc);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -994,6 +1130,7 @@ void cofactor_agg_destroy(cofactor_agg *a) {
   (void)hipFree(a->d_num);
   (void)hipFree(a->d_cat);
   (void)hipFree(a->d_host_dense);
+  for (auto &sp : a->sparse) sparse_store_free(sp);
   delete a;
 }
 
@@ -1014,6 +1151,7 @@ cofactor_status cofactor_agg_reset(cofactor_agg *a) {
     HIP_TRY(hipMemsetAsync(a->D.s, 0, sizeof(double) * std::max(1, a->L.n_s), st));
     HIP_TRY(hipMemsetAsync(a->D.p, 0, sizeof(unsigned long long) * std::max(1, a->L.n_p), st));
   }
+  for (auto &sp : a->sparse) sp.len = 0;
   return COFACTOR_OK;
 }
 
@@ -1312,6 +1450,7 @@ cofactor_status cofactor_agg_align_keys(cofactor_agg *a, const int32_t *keys_in,
   if (s != COFACTOR_OK) return s;
   s = cat_prepare(a);
   if (s != COFACTOR_OK) return s;
+  if (any_sparse_pair(a->L)) return fail(COFACTOR_ERR_UNSUPPORTED, "the state holds sparse pair tables (very high cardinalities): the dictionary-aligned table exchange does not cover them; exchange finalised blobs instead");
   hipStream_t st = a->ctx->stream;
   // the global key lists: whatever was handed in (any order, duplicates allowed: the
   // concatenation of all ranks' lists), sorted and made unique here
@@ -1445,6 +1584,7 @@ cofactor_status cofactor_agg_export_tables_device(cofactor_agg *a, double *d_out
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   if (a->stage_rows > 0) return fail(COFACTOR_ERR_INVALID, "export_tables: rows are still staged on the host (align first)");
+  if (any_sparse_pair(a->L)) return fail(COFACTOR_ERR_UNSUPPORTED, "the state holds sparse pair tables (very high cardinalities): the dictionary-aligned table exchange does not cover them; exchange finalised blobs instead");
   HIP_TRY(launch_cat_tables_export(a->L, a->D, d_out, a->ctx->stream));
   return COFACTOR_OK;
 }
@@ -1454,6 +1594,7 @@ cofactor_status cofactor_agg_import_tables_device(cofactor_agg *a, const double 
   if (a->m == 0 || !a->cat_ready) return COFACTOR_OK;
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
+  if (any_sparse_pair(a->L)) return fail(COFACTOR_ERR_UNSUPPORTED, "the state holds sparse pair tables (very high cardinalities): the dictionary-aligned table exchange does not cover them; exchange finalised blobs instead");
   HIP_TRY(launch_cat_tables_import(a->L, a->D, d_in, /*add=*/false, a->ctx->stream));
   a->dev_dirty = true;
   a->blob_cache_valid = false;

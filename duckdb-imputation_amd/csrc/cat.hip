@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void cat_relayout_kernel(CatLayout Lo, CatDevi
       int c1 = 0, rem = q;
       while (rem >= Lo.m - c1) { rem -= Lo.m - c1; c1++; }
       const int c2 = c1 + rem;
+      if (pair_is_sparse(Ln, q)) continue;         // (the host moves such a table into its sparse store)
       const int local = i - Lo.p_off[q];
       const int code1 = local / Lo.kc[c2], code2 = local % Lo.kc[c2];
       Dn.p[Ln.p_off[q] + code1 * Ln.kc[c2] + code2] = Do.p[i];
@@ -541,8 +542,8 @@ __global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t ro
         out[e] = CODE_NONE;
         if (e < cnt && ((keep >> e) & 1)) {
           const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], kv[e]);
-          if (code < 0 || code >= L.kc[c] || code >= 0xFFFF) D.flags[1] = 1;
-          else out[e] = (unsigned short)code;
+          if (code < 0 || code >= L.kc[c]) D.flags[1] = 1;
+          else if (code < 0xFFFF) out[e] = (unsigned short)code;   // (beyond: a wide column, never read from the cache)
         }
       }
       // stride is a multiple of 4: the store is 8-byte aligned

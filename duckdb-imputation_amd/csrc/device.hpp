@@ -73,7 +73,15 @@ struct CatLayout {
   int s_off[COFACTOR_MAX_CAT];    // sums:    s[s_off[c] + code * n + k]
   int p_off[MAX_PAIRS];           // pairs:   p[p_off[q] + code1 * kc[c2] + code2]
   int n_slots, n_cnt, n_s, n_p;
+  // pair tables kept as sorted (key1, key2) -> count lists outside this layout (sparse.hpp): no
+  // cells in p (their p_off equals the next pair's)
+  unsigned sparse_mask[(MAX_PAIRS + 31) / 32];
 };
+__host__ __device__ inline bool pair_is_sparse(const CatLayout &L, int q) { return (L.sparse_mask[q >> 5] >> (q & 31)) & 1u; }
+inline bool any_sparse_pair(const CatLayout &L) {
+  for (unsigned w : L.sparse_mask) if (w) return true;
+  return false;
+}
 
 struct CatDevice {
   unsigned long long *ht_slot;    // (1 << 32 | (uint32)key), 0 = empty

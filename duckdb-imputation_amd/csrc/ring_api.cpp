@@ -199,11 +199,16 @@ cofactor_status cofactor_agg_update_tvec_device(cofactor_agg *a, const cofactor_
   hipStream_t st = ctx->stream;
   if (!ctx->ring_red) HIP_TRY(hipMalloc((void **)&ctx->ring_red, sizeof(double) * 256));
   a->blob_cache_valid = false;
-  a->dev_dirty = true;
-  HIP_TRY(launch_tvec_dense(*v, ctx->ring_red, a->d_acc, a->d_kept, ctx->gram_grid, st));
   if (a->m > 0) {
     s = cat_dictionaries_with(a, [&]() { return launch_tvec_keys(*v, a->L, a->D, 0, st); });
     if (s != COFACTOR_OK) return s;
+    if (any_sparse_pair(a->L))                    // (before anything is added: the state stays consistent)
+      return fail(COFACTOR_ERR_UNSUPPORTED,
+                  "sum_triple into a state with sparse pair tables (very high cardinalities) is not implemented");
+  }
+  a->dev_dirty = true;
+  HIP_TRY(launch_tvec_dense(*v, ctx->ring_red, a->d_acc, a->d_kept, ctx->gram_grid, st));
+  if (a->m > 0) {
     HIP_TRY(launch_tvec_keys(*v, a->L, a->D, 1, st));
     a->cat_check_pending = true;
   }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "device.hpp"
+#include "sparse.hpp"
 #include "triple.hpp"
 
 // std::vector whose resize() leaves new doubles uninitialised (a blob of 1e8 doubles is written
@@ -54,6 +55,7 @@ struct cofactor_ctx {
   size_t code_cache_bytes = 0;
   unsigned *pair_tmp = nullptr;
   size_t pair_tmp_bytes = 0;
+  cofactor::SparseScratch sparse_sc;   // sort / merge buffers of the sparse pair tables
 };
 
 #define CTX_LOCK(ctxp) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxp)->mu)
@@ -73,6 +75,8 @@ struct cofactor_agg {
   // finalize's two-call protocol: the blob of the size query is kept for the fill call
   BlobVec blob_cache;
   bool blob_cache_valid = false;
+  // pair tables kept as sorted lists (L.sparse_mask): one store per column pair, empty for dense pairs
+  std::vector<cofactor::SparseStore> sparse;
   cofactor::CatLayout L{};
   cofactor::CatDevice D{};
   // host staging for update_host (pinned) and its device mirror, both double-buffered: while
@@ -113,7 +117,7 @@ struct DeviceGuard {
 
 // categorical state management shared with the ring ops (api.cpp)
 void cat_free(CatDevice &D);
-bool cat_finish_layout(CatLayout &L);
+bool cat_finish_layout(CatLayout &L, bool allow_sparse = false);
 cofactor_status cat_alloc(const CatLayout &L, CatDevice &D, bool fresh_counters, hipStream_t st);
 cofactor_status cat_regrow(cofactor_agg *a, const CatLayout &Lnew);
 cofactor_status cat_prepare(cofactor_agg *a);
