@@ -310,10 +310,30 @@ cofactor_status scratch_reserve(cofactor_ctx *ctx, T *&buf, size_t &have, size_t
   return COFACTOR_OK;
 }
 
-// The generic categorical path.  Everything in one launch when all tables fit LDS together;
-// otherwise keys -> 16-bit codes once, then count / sum passes over column subsets and pair passes
-// over runs of pair tables (LDS), one launch per pair table that is too big for LDS (u32 cells in
-// HBM, the only table written in that launch).
+// grows the per-workgroup pair slabs of the one-pass kernels
+cofactor_status ensure_pair_slabs(cofactor_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->pair_slab_bytes) return COFACTOR_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->pair_slabs);
+  ctx->pair_slabs = nullptr;
+  ctx->pair_slab_bytes = 0;
+  HIP_TRY(hipMalloc((void **)&ctx->pair_slabs, bytes));
+  ctx->pair_slab_bytes = bytes;
+  return COFACTOR_OK;
+}
+
+// The categorical tables of shapes the one-pass kernels do not take in one launch.
+//  * Everything in one launch of the LDS-atomic kernel when all tables fit LDS together and the
+//    one-hot MFMA kernel cannot help.
+//  * Otherwise per piece of <= 2^27 rows:
+//      - with <= 16 keys in every column (triple kind), the whole 256-row tiles of aligned columns
+//        get their key counts and per-key sums from fused2_kernel SUB-LAUNCHES over groups of
+//        <= 10 key columns x <= 10 numeric columns, and with m <= 10 their pair tables from one
+//        pairs-only launch of the same kernel;
+//      - what is left (any cardinality, m > 10 pairs, unaligned columns, the < 256-row tail):
+//        keys -> 16-bit codes once, then count / sum passes over column subsets and pair passes
+//        over runs of pair tables (LDS), one launch per pair table too big for LDS (u32 cells in
+//        HBM); columns past the 16-bit code cache and sparse pair tables as described there.
 cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows,
                                bool timed = true, const uint8_t *mask = nullptr) {
   cofactor_ctx *ctx = a->ctx;
@@ -345,8 +365,23 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
         }
     return COFACTOR_OK;
   };
+  // a column whose own count + sum tables exceed LDS: counts and sums with global atomics (old path)
+  const bool do_s = L.kind == 0 && L.n > 0;
+  bool sums_fit = true;
+  for (int c = 0; c < L.m; c++) sums_fit = sums_fit && cat_sums_lds_bytes(L, 1u << c, do_s) <= ctx->lds_budget;
+  // what the one-hot MFMA kernel can take: triple kind, every column <= 16 keys
+  const int groups_n = (L.n + 9) / 10, groups_m = (L.m + 9) / 10;
+  bool small_keys = L.kind == 0 && ctx->allow_fused && rows >= 16 * FUSED_TILE_ROWS && env_long("COFACTOR_NO_SUB", 0) == 0;
+  for (int c = 0; c < L.m; c++) small_keys = small_keys && a->nkeys_host[c] <= 16 && L.kc[c] == 16;
+  const bool mfma_sums = small_keys && do_s && sums_fit &&
+                         fused2_sub_fits((L.n + groups_n - 1) / groups_n, (L.m + groups_m - 1) / groups_m, mask != nullptr, L,
+                                         ctx->lds_max);
+  CatLayout Lp = L;                                // the key columns alone: the pairs-only launch
+  Lp.n = 0; Lp.n_s = 0;
+  const bool mfma_pairs = small_keys && (mfma_sums || !do_s) && L.m <= 10 &&
+                          fused2_applicable(Lp, a->nkeys_host, mask != nullptr, ctx->lds_max);
   const uint64_t piece = 1ull << 27;               // rows per code-cache fill / per sort
-  if (passes.size() == 1 && !hbm_needed) {         // one launch does all dense tables
+  if (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs) {   // one launch does all dense tables
     if (launch_cat_accumulate(num, cat, rows, L, a->D, passes[0], true, ctx->cat_grid, st, e0, e1, mask) != hipSuccess)
       return hip_fail(hipGetLastError(), "cat_accumulate");
     for (uint64_t off = 0; with_sparse && off < rows; off += piece) {
@@ -357,10 +392,6 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
     }
     return COFACTOR_OK;
   }
-  // a column whose own count + sum tables exceed LDS: counts and sums with global atomics (old path)
-  const bool do_s = L.kind == 0 && L.n > 0;
-  bool sums_fit = true;
-  for (int c = 0; c < L.m; c++) sums_fit = sums_fit && cat_sums_lds_bytes(L, 1u << c, do_s) <= ctx->lds_budget;
   if (e0) HIP_TRY(hipEventRecord(e0, st));
   for (uint64_t off = 0; off < rows; off += piece) {
     const uint64_t prows = std::min(piece, rows - off), stride = (prows + 3) / 4 * 4;
@@ -369,37 +400,95 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
     for (int k = 0; k < L.n; k++) pn.p[k] = num.p[k] + off;
     for (int c = 0; c < L.m; c++) pc.p[c] = cat.p[c] + off;
     const uint8_t *pmask = mask ? mask + off : nullptr;
-    cofactor_status s = scratch_reserve(ctx, ctx->code_cache, ctx->code_cache_bytes, (size_t)L.m * stride * 2);
-    if (s != COFACTOR_OK) return s;
-    HIP_TRY(launch_cat_codes(pc, prows, stride, L, a->D, pmask, ctx->code_cache, st));
-    if (sums_fit) {
-      unsigned sub = 0;
-      size_t used = 0;
-      for (int c = 0; c < L.m; c++) {
-        const size_t b = cat_sums_lds_bytes(L, 1u << c, do_s);
-        if (sub && used + b > ctx->lds_budget) {
-          HIP_TRY(launch_cat_sums(pn, ctx->code_cache, prows, stride, L, a->D, sub, ctx->cat_grid, st));
-          sub = 0; used = 0;
-        }
-        sub |= 1u << c; used += b;
-      }
-      if (sub) HIP_TRY(launch_cat_sums(pn, ctx->code_cache, prows, stride, L, a->D, sub, ctx->cat_grid, st));
-    } else {
-      CatPass base{};
-      base.do_cnt = 1; base.do_s = L.kind == 0;
-      base.col_mask = (L.m >= 32) ? 0xFFFFFFFFu : ((1u << L.m) - 1u);
-      base.dict_lds = hbm.dict_lds;
-      HIP_TRY(launch_cat_accumulate(pn, pc, prows, L, a->D, base, false, ctx->cat_grid, st, nullptr, nullptr, pmask));
+    // ---- whole tiles of aligned columns through the one-hot MFMA kernel ----
+    uint64_t body = 0;
+    if (mfma_sums || mfma_pairs) {
+      bool al = (reinterpret_cast<uintptr_t>(pmask) & 3) == 0;
+      for (int k = 0; k < L.n; k++) al = al && (reinterpret_cast<uintptr_t>(pn.p[k]) & 15) == 0;
+      for (int c = 0; c < L.m; c++) al = al && (reinterpret_cast<uintptr_t>(pc.p[c]) & 15) == 0;
+      if (al) body = prows - prows % FUSED_TILE_ROWS;
     }
-    if (L.kind == 0) {
+    // first row the code-cache kernels handle: counts + sums / pairs (without per-key sums the pairs
+    // launch has already counted the keys of the body)
+    const uint64_t s_from = (mfma_sums || (mfma_pairs && !do_s)) ? body : 0;
+    const uint64_t p_from = mfma_pairs ? body : 0;
+    if (body) {
+      const int grid = fused2_grid(ctx->cus, ctx->gram_grid, body);
+      if (mfma_pairs) {                            // pair tables, key counts, diagonal cells
+        cofactor_status s = ensure_pair_slabs(ctx, fused_slab_bytes(Lp, grid));
+        if (s != COFACTOR_OK) return s;
+        HIP_TRY(launch_fused2(NumCols{}, pc, body, Lp, a->D, grid, ctx->lds_max, ctx->partials, ctx->pair_slabs, nullptr,
+                              a->d_acc, st, nullptr, nullptr, pmask, nullptr));
+      }
+      if (mfma_sums)
+        for (int gm = 0, c0 = 0; gm < groups_m; gm++) {
+          const int mg = L.m / groups_m + (gm < L.m % groups_m ? 1 : 0);
+          int idx[10];
+          for (int c = 0; c < mg; c++) idx[c] = c0 + c;
+          for (int gn = 0, k0 = 0; gn < groups_n; gn++) {
+            const int ng = L.n / groups_n + (gn < L.n % groups_n ? 1 : 0);
+            HIP_TRY(launch_fused2_sub(pn, pc, body, L, a->D, k0, ng, idx, mg, /*do_cnt=*/gn == 0 && !mfma_pairs, grid,
+                                      ctx->lds_max, pmask, st));
+            k0 += ng;
+          }
+          c0 += mg;
+        }
+    }
+    // ---- the rest on 16-bit codes ----
+    const uint64_t c_from = std::min(s_from, p_from);
+    cofactor_status s = COFACTOR_OK;
+    if (c_from < prows) {
+      s = scratch_reserve(ctx, ctx->code_cache, ctx->code_cache_bytes, (size_t)L.m * stride * 2);
+      if (s != COFACTOR_OK) return s;
+      CatCols cc = pc;
+      for (int c = 0; c < L.m; c++) cc.p[c] = pc.p[c] + c_from;
+      HIP_TRY(launch_cat_codes(cc, prows - c_from, stride, L, a->D, pmask ? pmask + c_from : nullptr,
+                               ctx->code_cache + c_from, st));
+    }
+    if (s_from < prows) {
+      NumCols tn = pn;
+      CatCols tc = pc;
+      for (int k = 0; k < L.n; k++) tn.p[k] = pn.p[k] + s_from;
+      for (int c = 0; c < L.m; c++) tc.p[c] = pc.p[c] + s_from;
+      const unsigned short *tcodes = ctx->code_cache + s_from;
+      const uint64_t trows = prows - s_from;
+      if (sums_fit) {
+        unsigned sub = 0;
+        size_t used = 0;
+        for (int c = 0; c < L.m; c++) {
+          const size_t b = cat_sums_lds_bytes(L, 1u << c, do_s);
+          if (sub && used + b > ctx->lds_budget) {
+            HIP_TRY(launch_cat_sums(tn, tcodes, trows, stride, L, a->D, sub, ctx->cat_grid, st));
+            sub = 0; used = 0;
+          }
+          sub |= 1u << c; used += b;
+        }
+        if (sub) HIP_TRY(launch_cat_sums(tn, tcodes, trows, stride, L, a->D, sub, ctx->cat_grid, st));
+      } else {
+        CatPass base{};
+        base.do_cnt = 1; base.do_s = L.kind == 0;
+        base.col_mask = (L.m >= 32) ? 0xFFFFFFFFu : ((1u << L.m) - 1u);
+        base.dict_lds = hbm.dict_lds;
+        HIP_TRY(launch_cat_accumulate(tn, tc, trows, L, a->D, base, false, ctx->cat_grid, st, nullptr, nullptr,
+                                      pmask ? pmask + s_from : nullptr));
+      }
+    }
+    if (L.kind == 0 && p_from < prows) {
       // pair tables: runs that fit LDS together, then the big ones one by one
+      const unsigned short *tcodes = ctx->code_cache + p_from;
+      const uint64_t trows = prows - p_from;
+      NumCols tn = pn;
+      CatCols tc = pc;
+      for (int k = 0; k < L.n; k++) tn.p[k] = pn.p[k] + p_from;
+      for (int c = 0; c < L.m; c++) tc.p[c] = pc.p[c] + p_from;
+      const uint8_t *tmask = pmask ? pmask + p_from : nullptr;
       const int npairs = L.m * (L.m + 1) / 2;
       CatPass run{};
       size_t used = 0;
       std::vector<int> big;
       auto flush = [&]() -> hipError_t {
         if (run.p_cells == 0) return hipSuccess;
-        hipError_t e = launch_cat_pairs(ctx->code_cache, prows, stride, L, a->D, run, nullptr, ctx->cat_grid, st);
+        hipError_t e = launch_cat_pairs(tcodes, trows, stride, L, a->D, run, nullptr, ctx->cat_grid, st);
         run = CatPass{};
         used = 0;
         return e;
@@ -439,14 +528,14 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
         HIP_TRY(hipMemsetAsync(ctx->pair_tmp, 0, cells * 4, st));
         CatPass one{};
         one.pair_mask[qb >> 5] |= 1u << (qb & 31);
-        HIP_TRY(launch_cat_pairs(ctx->code_cache, prows, stride, L, a->D, one, ctx->pair_tmp, ctx->cat_grid, st));
+        HIP_TRY(launch_cat_pairs(tcodes, trows, stride, L, a->D, one, ctx->pair_tmp, ctx->cat_grid, st));
         HIP_TRY(launch_cat_fold_u32(ctx->pair_tmp, (long long)cells, a->D.p + L.p_off[qb], st));
       }
       if (any_wide)
-        HIP_TRY(launch_cat_accumulate(pn, pc, prows, L, a->D, wide, false, ctx->cat_grid, st, nullptr, nullptr, pmask));
-      s = sparse_step(pc, pmask, prows);
-      if (s != COFACTOR_OK) return s;
+        HIP_TRY(launch_cat_accumulate(tn, tc, trows, L, a->D, wide, false, ctx->cat_grid, st, nullptr, nullptr, tmask));
     }
+    s = sparse_step(pc, pmask, prows);
+    if (s != COFACTOR_OK) return s;
   }
   if (e1) HIP_TRY(hipEventRecord(e1, st));
   return COFACTOR_OK;
@@ -526,14 +615,9 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
     }
     const int grid = v1 ? fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows)
                         : fused2_grid(ctx->cus, ctx->gram_grid, main_rows);
-    const size_t slab = fused_slab_bytes(a->L, grid);
-    if (slab > ctx->pair_slab_bytes) {            // grow the per-workgroup pair slabs
-      HIP_TRY(hipStreamSynchronize(st));
-      (void)hipFree(ctx->pair_slabs);
-      ctx->pair_slabs = nullptr;
-      ctx->pair_slab_bytes = 0;
-      HIP_TRY(hipMalloc((void **)&ctx->pair_slabs, slab));
-      ctx->pair_slab_bytes = slab;
+    {
+      cofactor_status s = ensure_pair_slabs(ctx, fused_slab_bytes(a->L, grid));
+      if (s != COFACTOR_OK) return s;
     }
     unsigned *skip = nullptr;
     if (optimistic) {

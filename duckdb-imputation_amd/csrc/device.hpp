@@ -212,6 +212,23 @@ hipError_t launch_gather_tiles(const NumCols &num, const CatCols &cat, int n, in
 // ---- fused2.hip: the one-pass kernel for low-cardinality keys (<= 16 keys per column, <= 10 key
 // columns, triple and NB kinds, n >= 0); whole 256-row tiles of 16-byte aligned columns ------------
 bool fused2_applicable(const CatLayout &L, const int32_t *nkeys, bool masked, size_t lds_limit);
+// A sub-launch of the same kernel: key counts and per-key sums of a GROUP of key columns (<= 10)
+// against a GROUP of numeric columns (<= 10), nothing else (no Gram, no pair tables) — how shapes
+// beyond one launch (m > 10, or per-key-sum blocks past the register budget) get their per-key
+// sums off the LDS-atomic path.  Where the sub-tables sit in the aggregate's tables:
+struct F2Sub {
+  int s_goff[10];      // D.s index of (sub column c, code 0, numeric column 0 of the aggregate)
+  int cnt_goff[10];    // D.cnt index of (sub column c, code 0)
+  int n_full;          // numeric columns of the aggregate (row stride of its s tables)
+  int k0;              // first numeric column of the group
+  int do_cnt;          // add the key counts (one group of numeric columns does, the others do not)
+};
+// body rows (multiple of 256) of 16-byte aligned columns; every column of the group has <= 16 keys
+// and code capacity 16.  L: the aggregate's layout; cat_idx / m_sub: the key columns of the group.
+bool fused2_sub_fits(int n_sub, int m_sub, bool masked, const CatLayout &L, size_t lds_limit);
+hipError_t launch_fused2_sub(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
+                             const CatDevice &D, int k0, int n_sub, const int *cat_idx, int m_sub, bool do_cnt,
+                             int grid, size_t lds_limit, const uint8_t *mask, hipStream_t stream);
 int fused2_grid(int cus, int partials_cap_wgs, uint64_t rows);
 // rows one launch may take: the int32 pair accumulators of a wave hold 2^31 / 4096 rows
 inline uint64_t fused2_max_rows(int grid) { return (uint64_t)grid * 8000ull * FUSED_TILE_ROWS; }

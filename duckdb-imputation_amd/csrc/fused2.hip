@@ -55,6 +55,7 @@ constexpr int DIRECT_STRIDE = 260;
 
 // modes (template parameter MODE)
 constexpr int F2_PAIRS = 1, F2_SSUM = 2;   // pair tables; per-key sums of the numeric columns (key counts always)
+constexpr int F2_SUB = 4;                  // sub-launch (device.hpp: F2Sub): no Gram, tables land at sub's offsets
 
 struct F2Carve {          // byte offsets into the dynamic LDS block
   int ring, slot_bytes, zero, scratch, scratch_bytes, s, cnt, direct, slot, dcode, total;
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(F2_THREADS, 1) void fused2_kernel(NumCols num, CatC
                                                                unsigned *__restrict__ pair_slabs,
                                                                unsigned *__restrict__ skip,
                                                                const uint8_t *__restrict__ mask,
-                                                               unsigned long long *__restrict__ kept) {
-  constexpr bool PAIRS = (MODE & F2_PAIRS) != 0, SSUM = (MODE & F2_SSUM) != 0;
+                                                               unsigned long long *__restrict__ kept, F2Sub sub) {
+  constexpr bool PAIRS = (MODE & F2_PAIRS) != 0, SSUM = (MODE & F2_SSUM) != 0, SUB = (MODE & F2_SUB) != 0;
+  constexpr bool GRAM = NBLK > 0 && !SUB;
   constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
   constexpr int NT = PAIRS ? M * (M - 1) / 2 : 0;            // 16x16 pair blocks (c1 < c2)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(F2_THREADS, 1) void fused2_kernel(NumCols num, CatC
     // otherwise hoists every LDS read of the tile to the top and spills the accumulators)
     __builtin_amdgcn_sched_barrier(0);
     // -- the dense Gram straight from the raw tile --
-    if (NBLK > 0) {
+    if (GRAM) {
       const f32x4 *va = reinterpret_cast<const f32x4 *>(okA ? base + offA : lds + cv.zero + g_row);
       const f32x4 *vb = reinterpret_cast<const f32x4 *>(okB ? base + offB : lds + cv.zero + g_row);
 #pragma unroll
@@ -508,11 +510,11 @@ __global__ __launch_bounds__(F2_THREADS, 1) void fused2_kernel(NumCols num, CatC
       nslot = nslot >= ring ? nslot - ring : nslot;
       dma_tile(min(t + (uint64_t)(ring - 1) * G, ntiles - 1), nslot);     // past the end: a harmless re-load
       subtile(t, slot);
-      if (NBLK > 0 && ++since_g == G_FLUSH_TILES * RPM) { flush_gram(); since_g = 0; }
+      if (GRAM && ++since_g == G_FLUSH_TILES * RPM) { flush_gram(); since_g = 0; }
       if (++since_s == S_FLUSH_TILES) { flush_s(); since_s = 0; }
       slot = slot + 1 == ring ? 0 : slot + 1;
     }
-    if (NBLK > 0) flush_gram();
+    if (GRAM) flush_gram();
     flush_s();
   }
   wait_vmcnt_imm<0>();                                       // drain the re-loads before the ring is reused
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(F2_THREADS, 1) void fused2_kernel(NumCols num, CatC
     unsigned *slab = pair_slabs + (uint64_t)blockIdx.x * (uint64_t)L.n_p;
     for (int i = tid; i < L.n_p; i += F2_THREADS) slab[i] = l_p[i];
   }
-  if (NBLK > 0) {
+  if (GRAM) {
     __syncthreads();
     double *red = reinterpret_cast<double *>(lds + cv.ring) + (PAIRS ? (L.n_p + 1) / 2 : 0);
     double *mine = red + wave * GRAM_ACC_LEN;
@@ -560,6 +562,21 @@ __global__ __launch_bounds__(F2_THREADS, 1) void fused2_kernel(NumCols num, CatC
       partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
     }
   }
+  if (SUB) {
+    // the group's tables into the aggregate's: counts once per group of key columns, sums at
+    // numeric column sub.k0 + k of the full-width rows
+    if (sub.do_cnt)
+      for (int i = tid; i < 16 * m; i += F2_THREADS)
+        if (l_cnt[i]) atomicAdd(&D.cnt[sub.cnt_goff[i >> 4] + (i & 15)], (unsigned long long)l_cnt[i]);
+    if (SSUM)
+      for (int i = tid; i < L.n_s; i += F2_THREADS)
+        if (l_s[i] != 0.0) {
+          const int c = i / (16 * n), rem = i - c * 16 * n;
+          const int code = rem / n, k = rem - code * n;
+          unsafeAtomicAdd(&D.s[sub.s_goff[c] + code * sub.n_full + sub.k0 + k], l_s[i]);
+        }
+    return;
+  }
   // key counts: to cnt and to the diagonal cells (k, k) of the column's own pair table
   for (int i = tid; i < 16 * m; i += F2_THREADS)
     if (l_cnt[i]) {
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(F2_THREADS, 1) void fused2_kernel(NumCols num, CatC
   if (masked) {
     unsigned long long kk = n_kept;
     for (int off = 32; off > 0; off >>= 1) kk += __shfl_down(kk, off, 64);
-    if (lane == 0 && kk) atomicAdd(kept, kk);
+    if (lane == 0 && kk && kept) atomicAdd(kept, kk);
   }
 }
 
@@ -665,12 +682,12 @@ template <int NBLK, int NBB, int M, int MODE>
 hipError_t f2_launch_one(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                          const CatDevice &D, const F2Carve &cv, int ring, int grid, double *partials,
                          unsigned *slabs, unsigned *skip, const uint8_t *mask, unsigned long long *kept,
-                         hipStream_t stream) {
+                         hipStream_t stream, const F2Sub &sub = F2Sub{}) {
   hipError_t e = hipFuncSetAttribute((const void *)fused2_kernel<NBLK, NBB, M, MODE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, cv.total);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((fused2_kernel<NBLK, NBB, M, MODE>), dim3(grid), dim3(F2_THREADS), cv.total, stream,
-                     num, cat, rows, L, D, cv, ring, partials, slabs, skip, mask, kept);
+                     num, cat, rows, L, D, cv, ring, partials, slabs, skip, mask, kept, sub);
   return hipGetLastError();
 }
 
@@ -678,10 +695,10 @@ template <int NBLK, int NBB, int MODE>
 hipError_t f2_launch_m(int me, const NumCols &num, const CatCols &cat, uint64_t rows,
                        const CatLayout &L, const CatDevice &D, const F2Carve &cv, int ring, int grid,
                        double *partials, unsigned *slabs, unsigned *skip, const uint8_t *mask,
-                       unsigned long long *kept, hipStream_t stream) {
+                       unsigned long long *kept, hipStream_t stream, const F2Sub &sub = F2Sub{}) {
   switch (me) {
 #define CASE(M_) case M_: if constexpr (M_ * NBB <= F2_MAX_SBLOCKS) \
-      return f2_launch_one<NBLK, NBB, M_, MODE>(num, cat, rows, L, D, cv, ring, grid, partials, slabs, skip, mask, kept, stream); \
+      return f2_launch_one<NBLK, NBB, M_, MODE>(num, cat, rows, L, D, cv, ring, grid, partials, slabs, skip, mask, kept, stream, sub); \
     else break;
     CASE(2) CASE(4) CASE(6) CASE(8) CASE(10)
 #undef CASE
@@ -746,6 +763,69 @@ hipError_t launch_fused2(const NumCols &num, const CatCols &cat, uint64_t rows, 
   }
   if (L.n > 0) return launch_gram_fold(partials, grid, acc, stream);
   return hipSuccess;
+}
+
+namespace {
+// layout of a group: n_sub numeric and m_sub key columns, 16 codes each, dictionaries where the
+// aggregate's are
+CatLayout sub_layout(const CatLayout &L, int n_sub, const int *cat_idx, int m_sub) {
+  CatLayout S{};
+  S.n = n_sub; S.m = m_sub; S.kind = 0;
+  for (int c = 0; c < m_sub; c++) {
+    const int g = cat_idx ? cat_idx[c] : c;
+    S.ht_cap[c] = L.ht_cap[g]; S.ht_off[c] = L.ht_off[g]; S.kc[c] = 16;
+    S.cnt_off[c] = 16 * c; S.s_off[c] = 16 * n_sub * c;
+  }
+  S.n_slots = L.n_slots;                          // (the kernel copies all dictionaries to LDS)
+  S.n_cnt = 16 * m_sub; S.n_s = 16 * n_sub * m_sub; S.n_p = 0;
+  return S;
+}
+bool sub_shape(int n_sub, int m_sub, F2Shape &sh) {
+  if (n_sub < 1 || n_sub > 10 || m_sub < 1 || m_sub > 10) return false;
+  sh.nblk = (n_sub + 3) / 4;
+  sh.me = (m_sub + 1) / 2 * 2;
+  sh.mode = F2_SSUM | F2_SUB;
+  sh.nbb = (3 * n_sub + 1 + 15) / 16;
+  return sh.me * sh.nbb <= F2_MAX_SBLOCKS;
+}
+}  // namespace
+
+bool fused2_sub_fits(int n_sub, int m_sub, bool masked, const CatLayout &L, size_t lds_limit) {
+  F2Shape sh;
+  if (!sub_shape(n_sub, m_sub, sh)) return false;
+  const CatLayout S = sub_layout(L, n_sub, nullptr, m_sub);
+  return f2_ring(S, sh, masked, lds_limit) >= 3;
+}
+
+hipError_t launch_fused2_sub(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
+                             const CatDevice &D, int k0, int n_sub, const int *cat_idx, int m_sub, bool do_cnt,
+                             int grid, size_t lds_limit, const uint8_t *mask, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  F2Shape sh;
+  if (!sub_shape(n_sub, m_sub, sh) || rows % TR != 0) return hipErrorInvalidValue;
+  const CatLayout S = sub_layout(L, n_sub, cat_idx, m_sub);
+  const bool masked = mask != nullptr;
+  const int ring = f2_ring(S, sh, masked, lds_limit);
+  if (ring < 3) return hipErrorInvalidValue;
+  const F2Carve cv = f2_carve(S, sh, masked, ring);
+  NumCols ns{};
+  CatCols cs{};
+  F2Sub sub{};
+  for (int k = 0; k < n_sub; k++) ns.p[k] = num.p[k0 + k];
+  for (int c = 0; c < m_sub; c++) {
+    cs.p[c] = cat.p[cat_idx[c]];
+    sub.s_goff[c] = L.s_off[cat_idx[c]];
+    sub.cnt_goff[c] = L.cnt_off[cat_idx[c]];
+  }
+  sub.n_full = L.n; sub.k0 = k0; sub.do_cnt = do_cnt ? 1 : 0;
+  hipError_t e = hipErrorInvalidValue;
+#define GO(NBLK_, NBB_) e = f2_launch_m<NBLK_, NBB_, F2_SSUM | F2_SUB>(sh.me, ns, cs, rows, S, D, cv, ring, grid, nullptr, nullptr, nullptr, mask, nullptr, stream, sub)
+  switch (10 * sh.nblk + sh.nbb) {
+    case 11: GO(1, 1); break; case 21: GO(2, 1); break; case 22: GO(2, 2); break; case 32: GO(3, 2); break;
+    default: break;
+  }
+#undef GO
+  return e;
 }
 
 hipError_t launch_gather_units(const NumCols &num, const CatCols &cat, int n, int m, int unit, const unsigned *list,

@@ -692,3 +692,42 @@ def test_both_one_pass_kernels_exact(monkeypatch, pref, n, m, nb, keys):
         assert blob_to_dict(agg.finalize()) == blob_to_dict(want.finalize()), ("second", use_mask)
         agg.close()
     c2.close()
+
+
+@pytest.mark.parametrize("n,m", [(20, 20), (20, 10), (13, 11), (3, 12), (10, 20)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_wide_shapes_take_their_per_key_sums_through_sub_launches(monkeypatch, n, m, masked):
+    """Shapes beyond one one-pass launch (m > 10, or too many per-key-sum blocks) with <= 16 keys per
+    column: key counts and per-key sums come from fused2_kernel sub-launches over column groups
+    (whole 256-row tiles) plus the LDS-atomic kernel for the tail; pairs from the code cache.
+    Exact against the faithful oracle on integer data, with and without a row filter, in two
+    batches (the second brings new keys), and equal to the run with the sub-launches switched off."""
+    import torch
+    rng = np.random.default_rng(100 * n + m + masked)
+    blobs = []
+    for no_sub in ("0", "1"):
+        monkeypatch.setenv("COFACTOR_NO_SUB", no_sub)
+        c = cofactor_hip.Context(0)
+        agg = c.aggregate(n, m)
+        ref = orc.State(orc.FAITHFUL)
+        r = np.random.default_rng(100 * n + m + masked)
+        for rows, k in ((70_001, 9), (33_333, 16)):
+            num = [r.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+            cat = [(r.integers(0, k, rows) * 5 - 20).astype(np.int32) for _ in range(m)]
+            dn = [torch.from_numpy(x).cuda() for x in num]
+            dc = [torch.from_numpy(x).cuda() for x in cat]
+            if masked:
+                keep = (r.random(rows) < 0.7).astype(np.uint8)
+                torch.cuda.synchronize()
+                agg.update_device_masked(dn, dc, torch.from_numpy(keep).cuda())
+                sel = keep.astype(bool)
+                ref.update([x[sel] for x in num], [x[sel] for x in cat])
+            else:
+                torch.cuda.synchronize()
+                agg.update_device(dn, dc)
+                ref.update(num, cat)
+        blob = agg.finalize()
+        agg.close(); c.close()
+        assert blob_to_dict(blob) == blob_to_dict(ref.finalize())
+        blobs.append(blob)
+    assert np.array_equal(blobs[0], blobs[1])
