@@ -702,51 +702,122 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
   return COFACTOR_OK;
 }
 
-// (Re)allocates the double-buffered staging area for `cap` rows per buffer.  Only called with
-// both buffers empty on the host side; waits for copies still reading the old one.
-cofactor_status stage_alloc(cofactor_agg *a, uint64_t cap) {
-  CTX_LOCK(a->ctx);
-  if (a->stage_cap) {
-    a->stage_cap = 0;                              // a failure below must not leave a capacity without buffers
-    HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+// Hands the state's staging block to the context's pool (or frees it when the pool is full).
+// The caller has made sure no copy or kernel still uses it.
+static void stage_release(cofactor_agg *a) {
+  if (!a->stage_cap) return;
+  cofactor_ctx *ctx = a->ctx;
+  const size_t bytes = (size_t)(a->n + a->m) * 2 * a->stage_cap * 4;
+  if (ctx->stage_pool_bytes + bytes <= ((size_t)4 << 30) && ctx->stage_pool.size() < 256) {
+    ctx->stage_pool.push_back({a->n, a->m, a->stage_cap, a->h_num, a->d_num, a->h_cat, a->d_cat});
+    ctx->stage_pool_bytes += bytes;
+  } else {
     if (a->h_num) (void)hipHostFree(a->h_num);
     if (a->h_cat) (void)hipHostFree(a->h_cat);
     (void)hipFree(a->d_num);
     (void)hipFree(a->d_cat);
-    a->h_num = nullptr; a->h_cat = nullptr; a->d_num = nullptr; a->d_cat = nullptr;
-    a->stage_busy[0] = a->stage_busy[1] = false;
   }
-  if (a->n) {
-    HIP_TRY(hipHostMalloc((void **)&a->h_num, sizeof(float) * 2 * a->n * cap, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&a->d_num, sizeof(float) * 2 * a->n * cap));
+  a->h_num = nullptr; a->h_cat = nullptr; a->d_num = nullptr; a->d_cat = nullptr;
+  a->stage_cap = 0;
+}
+
+// (Re)allocates the double-buffered staging area for `cap` rows per buffer.  Only called with
+// both buffers empty on the host side; waits for the state's OWN copies and kernels still using the
+// old one (not for the whole stream: other worker threads keep it busy).
+cofactor_status stage_alloc(cofactor_agg *a, uint64_t cap) {
+  for (int b = 0; b < 2; b++)
+    if (a->stage_busy[b]) {
+      HIP_TRY(hipEventSynchronize(a->stage_ev[b]));
+      a->stage_busy[b] = false;
+    }
+  CTX_LOCK(a->ctx);
+  stage_release(a);                                // (stage_cap = 0: a failure below leaves no capacity without buffers)
+  cofactor_ctx *ctx = a->ctx;
+  for (size_t i = 0; i < ctx->stage_pool.size(); i++) {
+    const auto &blk = ctx->stage_pool[i];
+    if (blk.n == a->n && blk.m == a->m && blk.cap == cap) {
+      a->h_num = blk.h_num; a->d_num = blk.d_num; a->h_cat = blk.h_cat; a->d_cat = blk.d_cat;
+      ctx->stage_pool_bytes -= (size_t)(a->n + a->m) * 2 * cap * 4;
+      ctx->stage_pool.erase(ctx->stage_pool.begin() + (long)i);
+      break;
+    }
   }
-  if (a->m) {
-    HIP_TRY(hipHostMalloc((void **)&a->h_cat, sizeof(int32_t) * 2 * a->m * cap, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&a->d_cat, sizeof(int32_t) * 2 * a->m * cap));
+  if (!a->h_num && !a->h_cat) {
+    float *hn = nullptr, *dn = nullptr;
+    int32_t *hc = nullptr, *dc = nullptr;
+    hipError_t e = hipSuccess;
+    if (a->n) {
+      e = hipHostMalloc((void **)&hn, sizeof(float) * 2 * a->n * cap, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipMalloc((void **)&dn, sizeof(float) * 2 * a->n * cap);
+    }
+    if (a->m && e == hipSuccess) {
+      e = hipHostMalloc((void **)&hc, sizeof(int32_t) * 2 * a->m * cap, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipMalloc((void **)&dc, sizeof(int32_t) * 2 * a->m * cap);
+    }
+    if (e != hipSuccess) {
+      if (hn) (void)hipHostFree(hn);
+      if (hc) (void)hipHostFree(hc);
+      (void)hipFree(dn);
+      (void)hipFree(dc);
+      return hip_fail(e, "staging buffers");
+    }
+    a->h_num = hn; a->d_num = dn; a->h_cat = hc; a->d_cat = dc;
   }
   for (auto &e : a->stage_ev)
-    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));   // (a waiting worker thread sleeps)
   a->stage_cap = cap;
   a->stage_buf = 0;
   return COFACTOR_OK;
 }
 
+static cofactor_status stage_enqueue(cofactor_agg *a);
+
 cofactor_status stage_flush(cofactor_agg *a) {
   if (a->stage_rows == 0) return COFACTOR_OK;
+  const int b = a->stage_buf;
+  {
+    cofactor_status s = stage_enqueue(a);          // (holds the context lock)
+    if (s != COFACTOR_OK) return s;
+  }
+  // The buffer filled next must have left the host.  Waited for WITHOUT the context lock: other
+  // worker threads keep enqueueing their own flushes meanwhile.
+  if (a->stage_busy[b ^ 1]) {
+    HIP_TRY(hipEventSynchronize(a->stage_ev[b ^ 1]));
+    a->stage_busy[b ^ 1] = false;
+  }
+  return COFACTOR_OK;
+}
+
+static cofactor_status stage_enqueue(cofactor_agg *a) {
   CTX_LOCK(a->ctx);
   hipStream_t st = a->ctx->stream;
   const uint64_t cap = a->stage_cap, rows = a->stage_rows;
   const int b = a->stage_buf;
   NumCols num{};
   CatCols cat{};
+  // a buffer is [column][cap]: when it is (nearly) full the columns go up in ONE copy (20 copies
+  // of 1 MB reach about half of what the link gives a single 20 MB copy)
+  const bool whole = rows * 8 >= cap * 7 && env_long("COFACTOR_STAGE_SPLIT", 0) == 0;
+  if (whole) {
+    if (a->n) {
+      const uint64_t off = (uint64_t)b * a->n * cap;
+      HIP_TRY(hipMemcpyAsync(a->d_num + off, a->h_num + off, ((uint64_t)(a->n - 1) * cap + rows) * sizeof(float),
+                             hipMemcpyHostToDevice, st));
+    }
+    if (a->m) {
+      const uint64_t off = (uint64_t)b * a->m * cap;
+      HIP_TRY(hipMemcpyAsync(a->d_cat + off, a->h_cat + off, ((uint64_t)(a->m - 1) * cap + rows) * sizeof(int32_t),
+                             hipMemcpyHostToDevice, st));
+    }
+  }
   for (int k = 0; k < a->n; k++) {
     const uint64_t off = ((uint64_t)b * a->n + k) * cap;
-    HIP_TRY(hipMemcpyAsync(a->d_num + off, a->h_num + off, rows * sizeof(float), hipMemcpyHostToDevice, st));
+    if (!whole) HIP_TRY(hipMemcpyAsync(a->d_num + off, a->h_num + off, rows * sizeof(float), hipMemcpyHostToDevice, st));
     num.p[k] = a->d_num + off;
   }
   for (int c = 0; c < a->m; c++) {
     const uint64_t off = ((uint64_t)b * a->m + c) * cap;
-    HIP_TRY(hipMemcpyAsync(a->d_cat + off, a->h_cat + off, rows * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!whole) HIP_TRY(hipMemcpyAsync(a->d_cat + off, a->h_cat + off, rows * sizeof(int32_t), hipMemcpyHostToDevice, st));
     cat.p[c] = a->d_cat + off;
   }
   cofactor_status s = update_device_impl(a, num, cat, rows);
@@ -755,10 +826,6 @@ cofactor_status stage_flush(cofactor_agg *a) {
   a->stage_busy[b] = true;
   a->stage_buf = b ^ 1;
   a->stage_rows = 0;
-  if (a->stage_busy[b ^ 1]) {                      // the buffer filled next must have left the host
-    HIP_TRY(hipEventSynchronize(a->stage_ev[b ^ 1]));
-    a->stage_busy[b ^ 1] = false;
-  }
   return COFACTOR_OK;
 }
 
@@ -1099,6 +1166,12 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->code_cache);
   (void)hipFree(ctx->pair_tmp);
   sparse_scratch_free(ctx->sparse_sc);
+  for (auto &blk : ctx->stage_pool) {
+    if (blk.h_num) (void)hipHostFree(blk.h_num);
+    if (blk.h_cat) (void)hipHostFree(blk.h_cat);
+    (void)hipFree(blk.d_num);
+    (void)hipFree(blk.d_cat);
+  }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1207,12 +1280,9 @@ void cofactor_agg_destroy(cofactor_agg *a) {
   (void)hipFree(a->d_acc);
   (void)hipFree(a->d_kept);
   if (a->cat_ready) cat_free(a->D);
-  if (a->h_num) (void)hipHostFree(a->h_num);
-  if (a->h_cat) (void)hipHostFree(a->h_cat);
+  stage_release(a);                                // (the stream is idle: nothing uses the block)
   for (auto &e : a->stage_ev)
     if (e) (void)hipEventDestroy(e);
-  (void)hipFree(a->d_num);
-  (void)hipFree(a->d_cat);
   (void)hipFree(a->d_host_dense);
   for (auto &sp : a->sparse) sparse_store_free(sp);
   delete a;

@@ -56,6 +56,12 @@ struct cofactor_ctx {
   unsigned *pair_tmp = nullptr;
   size_t pair_tmp_bytes = 0;
   cofactor::SparseScratch sparse_sc;   // sort / merge buffers of the sparse pair tables
+  // Staging blocks (pinned + device, both buffers of a state) handed back by states that were
+  // destroyed or outgrew them, reused by the next state of the same shape: the worker threads of
+  // the next query do not pin 40 MB each again.
+  struct StageBlock { int n, m; uint64_t cap; float *h_num, *d_num; int32_t *h_cat, *d_cat; };
+  std::vector<StageBlock> stage_pool;
+  size_t stage_pool_bytes = 0;
 };
 
 #define CTX_LOCK(ctxp) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxp)->mu)

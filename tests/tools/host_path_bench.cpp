@@ -24,7 +24,9 @@ int main(int argc, char **argv) {
   for (auto &c : cat) for (auto &v : c) v = (int32_t)(rng() & 15);
   cofactor_ctx *ctx = nullptr;
   if (cofactor_ctx_create(0, &ctx) != COFACTOR_OK) { fprintf(stderr, "%s\n", cofactor_last_error()); return 1; }
-  for (uint64_t chunk : {(uint64_t)2048, (uint64_t)1 << 20}) {
+  // every configuration twice: the second pass is what the next query sees (staging blocks come
+  // from the context's pool instead of being pinned again)
+  for (uint64_t chunk : {(uint64_t)2048, (uint64_t)2048, (uint64_t)1 << 20, (uint64_t)1 << 20}) {
     std::vector<cofactor_agg *> aggs(threads, nullptr);
     for (auto &a : aggs) {                     // warm-up: staging buffers, dictionaries, code objects
       cofactor_agg_create(ctx, n, m, COFACTOR_TRIPLE, &a);
