@@ -46,6 +46,18 @@ def _hash_torch(torch, seed, stream, lo, hi, device):
     return z ^ ((z >> 31) & ((1 << 33) - 1))
 
 
+def _column(torch, rows, dtype, device, stream):
+    """An uninitialised device column.  COFACTOR_BENCH_STAGGER=<bytes> (multiple of 16; experiment
+    knob) starts column `stream` that many bytes x (stream % 32) into its allocation, so that the
+    same row of different columns does not sit at the same offset modulo 2 MiB."""
+    import os
+    stagger = int(os.environ.get("COFACTOR_BENCH_STAGGER", "0"))
+    pad = (stagger * (stream % 32)) // 4
+    if pad == 0:
+        return torch.empty(rows, dtype=dtype, device=device)
+    return torch.empty(rows + pad, dtype=dtype, device=device)[pad:]
+
+
 def _fill(torch, out, seed, stream, lo, convert):
     rows = out.numel()
     for a in range(0, rows, CHUNK):
@@ -56,20 +68,20 @@ def _fill(torch, out, seed, stream, lo, convert):
 
 def uniform(torch, seed, stream, lo, hi, device):
     """float32 uniform [0, 1): the top 24 bits of the hash times 2^-24."""
-    out = torch.empty(hi - lo, dtype=torch.float32, device=device)
+    out = _column(torch, hi - lo, torch.float32, device, stream)
     return _fill(torch, out, seed, stream, lo,
                  lambda z: ((z >> 40) & 0xFFFFFF).to(torch.float32) * (1.0 / (1 << 24)))
 
 
 def integers(torch, seed, stream, lo, hi, K, device):
     """int32 uniform in [0, K) (K <= 2^24; the top 24 bits of the hash modulo K)."""
-    out = torch.empty(hi - lo, dtype=torch.int32, device=device)
+    out = _column(torch, hi - lo, torch.int32, device, stream)
     return _fill(torch, out, seed, stream, lo, lambda z: (((z >> 40) & 0xFFFFFF) % K).to(torch.int32))
 
 
 def small_ints(torch, seed, stream, lo, hi, K, device):
     """float32 whole numbers in [0, K)."""
-    out = torch.empty(hi - lo, dtype=torch.float32, device=device)
+    out = _column(torch, hi - lo, torch.float32, device, stream)
     return _fill(torch, out, seed, stream, lo, lambda z: (((z >> 40) & 0xFFFFFF) % K).to(torch.float32))
 
 

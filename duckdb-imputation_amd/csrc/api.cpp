@@ -1231,16 +1231,18 @@ cofactor_status cofactor_ctx_calibrate(cofactor_ctx *ctx, uint64_t bytes, int re
   if (e == hipSuccess) e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
   double out[2] = {0, 0};
+  const int cal_grid = 16 * ctx->cus;
   for (int mode = 0; mode < 2 && e == hipSuccess; mode++) {
     const bool copy = mode == 0;
-    e = launch_calibration(src, dst, bytes, ctx->gram_grid, copy, ctx->stream);     // warm-up
+    e = launch_calibration(src, dst, bytes, cal_grid, copy, ctx->stream);     // warm-up
     if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
-    for (int r = 0; r < reps && e == hipSuccess; r++) e = launch_calibration(src, dst, bytes, ctx->gram_grid, copy, ctx->stream);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = launch_calibration(src, dst, bytes, cal_grid, copy, ctx->stream);
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e == hipSuccess && ms > 0) out[mode] = (copy ? 2.0 : 1.0) * (double)bytes * reps / (ms * 1e-3) / 1e9;
+    if (e == hipSuccess && ms > 0)
+      out[mode] = (copy ? 2.0 : 1.0) * (double)calibration_bytes(bytes, cal_grid) * reps / (ms * 1e-3) / 1e9;
   }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);

@@ -59,6 +59,7 @@ hipError_t launch_dense_import(const double *in, int n, int kind, double *acc, u
 
 // calibration kernels (cofactor_ctx_calibrate): float4 copy / read-only stream over `bytes`
 hipError_t launch_calibration(const void *src, void *dst, uint64_t bytes, int grid, bool copy, hipStream_t stream);
+uint64_t calibration_bytes(uint64_t bytes, int grid);   // bytes one launch actually reads
 
 // ---- categorical tables -----------------------------------------------------------------------
 constexpr int MAX_PAIRS = COFACTOR_MAX_CAT * (COFACTOR_MAX_CAT + 1) / 2;

@@ -72,10 +72,13 @@ __host__ __device__ constexpr int gram_ring_depth(int n) {
   return n <= 4 ? 5 : (n <= 8 ? 3 : 2);
 }
 
+// (experiment knob: COFACTOR_GRAM_CHUNKED)
+static int g_gram_chunked = [] { const char *v = getenv("COFACTOR_GRAM_CHUNKED"); return v ? atoi(v) : 0; }();
+
 template <int N, bool ALIGNED, bool MASKED>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64_t rows,
                                                             double *__restrict__ partials,
-                                                            const uint8_t *__restrict__ mask_arg) {
+                                                            const uint8_t *__restrict__ mask_arg, int chunked) {
   const uint8_t *__restrict__ mask = MASKED ? mask_arg : nullptr;   // unfiltered variant: no filter bytes are read
   constexpr int NB = (N + 3) / 4;
   constexpr int NPAIR = NB * (NB + 1) / 2;
@@ -191,25 +194,32 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   const int ablate = g_gram_ablate;
 #endif
   const uint64_t G = gridDim.x;
-  uint64_t t = blockIdx.x;
-  if (t < nfull) {
+  // tile order: grid-stride (tile b, b + G, ...) or one contiguous run of tiles per workgroup
+  uint64_t t = blockIdx.x, tstep = G, tend = nfull;
+  if (chunked & 1) {
+    const uint64_t per = (nfull + G - 1) / G;
+    t = min((uint64_t)blockIdx.x * per, nfull);
+    tend = min(t + per, nfull);
+    tstep = 1;
+  }
+  if (t < tend) {
     float4 pre[DEPTH][LD];
     unsigned pmask[DEPTH];
 #pragma unroll
-    for (int r = 0; r < DEPTH; r++) fetch(pre[r], pmask[r], min(t + r * G, nfull - 1));
-    while (t < nfull) {
+    for (int r = 0; r < DEPTH; r++) fetch(pre[r], pmask[r], min(t + r * tstep, tend - 1));
+    while (t < tend) {
 #pragma unroll
       for (int r = 0; r < DEPTH; r++) {           // tile t sits in ring slot r
         park(pre[r], pmask[r]);
         __syncthreads();
-        fetch(pre[r], pmask[r], min(t + DEPTH * G, nfull - 1));   // flies under DEPTH tiles of MFMAs
+        fetch(pre[r], pmask[r], min(t + DEPTH * tstep, tend - 1));   // flies under DEPTH tiles of MFMAs
 #ifdef COFACTOR_DEV_ABLATE
         if (ablate == 0)
 #endif
         crunch();
         __syncthreads();                          // everyone done reading before the next park()
-        t += G;
-        if (t >= nfull) break;
+        t += tstep;
+        if (t >= tend) break;
       }
     }
   }
@@ -254,6 +264,194 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   }
 }
 
+// ---- gram_dma_kernel: the same arithmetic, tiles fetched by LDS-DMA (experiment, opt-in) ---------------
+// gram_kernel's fetch goes global -> VGPRs -> ds_write ("park") with two barriers per tile; a
+// loads-only run of that structure stops at ~5.8 TB/s where the bare loads reach 6.6
+// (tests/tools/cols_probe.hip).  Here `global_load_lds_dwordx4` writes each wave's 1 KiB of a
+// column straight into a ring of raw tiles in LDS: no park, no VGPR ring, ONE barrier per tile.
+// Whole tiles of 16-byte aligned columns without a row filter; launch_gram sends everything else
+// (tail, filter, unaligned columns) through gram_kernel.
+// Result (20_0, 1e9 rows): 5.0 / 5.7 / 5.95 TB/s at 1 / 2 / 3 workgroups per CU whatever the ring
+// depth (2..7) and whether 4 or 8 waves share a tile — the same ~6 TB/s as gram_kernel, so the
+// park and the second barrier are not what separates the kernel from the bare loads.  Kept behind
+// COFACTOR_GRAM_DMA=1 (tests/test_gpu_fullsize.py runs it).
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int DMA_COLB = 1040;                   // bytes of one column in a ring slot: 1 KiB + 16 (bank spread)
+
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
+  // (as an asm statement: the builtin makes hipcc wait vmcnt(0) before the next LDS access, i.e.
+  // drain the whole ring; M0 is written in the statement that reads it)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int K>
+__device__ __forceinline__ void dma_wait_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); }
+__device__ __forceinline__ void dma_wait(int k) {          // wave-uniform k
+  switch (k) {
+#define W(K) case K: dma_wait_imm<K>(); break;
+    W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16) W(17) W(18) W(19)
+    W(20) W(21) W(22) W(23) W(24) W(25) W(26) W(27) W(28) W(29) W(30) W(31) W(32) W(33) W(34) W(35) W(36) W(37)
+    W(38) W(39) W(40)
+#undef W
+    default: dma_wait_imm<0>(); break;
+  }
+}
+
+// WAVES waves share a tile: 256 / WAVES rows each (8 waves: twice the waves per CU for the same LDS,
+// half the latency chain per wave and tile).
+template <int N, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gram_dma_kernel(NumCols cols, uint64_t nfull, double *__restrict__ partials,
+                                                              int ring) {
+  constexpr int THREADS = 64 * WAVES, RW = GRAM_TILE_ROWS / WAVES;   // rows of a tile per wave
+  constexpr int NB = (N + 3) / 4;
+  constexpr int NPAIR = NB * (NB + 1) / 2;
+  constexpr int RPM = gram_rows_per_mfma(N);
+  constexpr int SLOT = N * DMA_COLB;
+  constexpr int MAXCPW = (N + WAVES - 1) / WAVES;
+  static_assert(RW >= 4 * RPM, "a wave needs at least one full round of row groups");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];   // [ring][SLOT] | zero column
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char *zero = dlds + ring * SLOT;
+  for (int i = tid; i < DMA_COLB / 4; i += THREADS) reinterpret_cast<unsigned *>(zero)[i] = 0u;
+
+  int colA = -1, colB = -1, rsub = 0;
+  {
+    const int b = lane >> 2, t = lane & 3;
+    if (b < RPM * NPAIR) {
+      rsub = b / NPAIR;
+      int bi = 0, rem = b % NPAIR;
+      while (rem >= NB - bi) { rem -= NB - bi; bi++; }
+      colA = 4 * bi + t;
+      colB = 4 * (bi + rem) + t;
+    }
+  }
+  const bool okA = colA >= 0 && colA < N, okB = colB >= 0 && colB < N;   // else: the zero column
+  const int g_row = (wave * RW + 4 * rsub) * 4;
+  const int offA = colA * DMA_COLB + g_row, offB = colB * DMA_COLB + g_row;
+
+  // this wave's columns: wave, wave + WAVES, ... (< N); its waits count its own DMA instructions
+  const int cpw = wave < N ? (N - wave + WAVES - 1) / WAVES : 0;
+  const unsigned lds0 = (unsigned)(unsigned long long)(lds_void_t *)dlds;
+  auto dma_tile = [&](uint64_t t, int slot) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT);
+#pragma unroll
+    for (int i = 0; i < MAXCPW; i++)
+      if (i < cpw) {
+        const int c = wave + WAVES * i;
+        dma16(reinterpret_cast<const unsigned char *>(cols.p[c]) + t * (GRAM_TILE_ROWS * 4) + 16 * lane,
+              __builtin_amdgcn_readfirstlane(base + c * DMA_COLB));
+      }
+  };
+
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  f32x2 ls_lo = {0.f, 0.f}, ls_hi = {0.f, 0.f};
+  double dq0 = 0, dq1 = 0, dq2 = 0, dq3 = 0, dl = 0;
+  int since_flush = 0;
+  auto flush = [&]() {
+    dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
+    dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
+    dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
+    dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
+    dl += (double)((ls_lo[0] + ls_lo[1]) + (ls_hi[0] + ls_hi[1]));
+    acc0 = acc1 = acc2 = acc3 = f32x4{0, 0, 0, 0};
+    ls_lo = ls_hi = f32x2{0.f, 0.f};
+  };
+  __syncthreads();                                           // zero column written
+
+  const uint64_t G = gridDim.x;
+  {
+    uint64_t t = blockIdx.x;                                 // (blockIdx.x < nfull: the launcher sizes the grid)
+    for (int r = 0; r < ring - 1; r++) dma_tile(min(t + r * G, nfull - 1), r);
+    int slot = 0;
+    const int keep = (ring - 2) * cpw;                       // DMA instructions that may stay in flight at the wait
+    for (; t < nfull; t += G) {
+      dma_wait(keep);                                        // this wave's part of tile t has landed ...
+      __builtin_amdgcn_s_barrier();                          // ... and so has everybody else's; slot - 1 is free
+      int nslot = slot + ring - 1;
+      nslot = nslot >= ring ? nslot - ring : nslot;
+      dma_tile(min(t + (uint64_t)(ring - 1) * G, nfull - 1), nslot);      // past the end: a harmless re-load
+      const unsigned char *base = dlds + slot * SLOT;
+      const f32x4 *va = reinterpret_cast<const f32x4 *>(okA ? base + offA : zero + g_row);
+      const f32x4 *vb = reinterpret_cast<const f32x4 *>(okB ? base + offB : zero + g_row);
+#pragma unroll 4
+      for (int it = 0; it < RW / 4 / RPM; it++) {
+        const f32x4 a = va[it * RPM], b = vb[it * RPM];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc3, 0, 0, 0);
+        ls_lo += __builtin_shufflevector(a, a, 0, 1);
+        ls_hi += __builtin_shufflevector(a, a, 2, 3);
+      }
+      if (++since_flush == FLUSH_TILES * RPM) { flush(); since_flush = 0; }
+      slot = slot + 1 == ring ? 0 : slot + 1;
+    }
+  }
+  flush();
+  dma_wait_imm<0>();                                         // drain the re-loads before the ring is reused
+  __syncthreads();
+
+  double *red = reinterpret_cast<double *>(dlds);            // WAVES x 320 doubles (the ring is free)
+  double *mine = red + wave * GRAM_ACC_LEN;
+  mine[0 * 64 + lane] = dq0;
+  mine[1 * 64 + lane] = dq1;
+  mine[2 * 64 + lane] = dq2;
+  mine[3 * 64 + lane] = dq3;
+  mine[4 * 64 + lane] = dl;
+  __syncthreads();
+  for (int i = tid; i < GRAM_ACC_LEN; i += THREADS) {
+    const int ln = i & 63;
+    double v = 0;
+    if (ln < 4 * NPAIR)
+#pragma unroll
+      for (int rs = 0; rs < RPM; rs++) {
+        const int j = i + 4 * NPAIR * rs;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) v += red[w * GRAM_ACC_LEN + j];     // fixed order
+      }
+    partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+// shape of the DMA kernel for n columns: waves per workgroup, ring depth, workgroups per CU (160 KB
+// of LDS per CU)
+static void gram_dma_shape(int n, int &waves, int &ring, int &wgs_per_cu, size_t &lds) {
+  static const int env_ring = [] { const char *v = getenv("COFACTOR_GRAM_DMA_RING"); return v ? atoi(v) : 0; }();
+  static const int env_wgs = [] { const char *v = getenv("COFACTOR_GRAM_DMA_WGS"); return v ? atoi(v) : 0; }();
+  static const int env_waves = [] { const char *v = getenv("COFACTOR_GRAM_DMA_WAVES"); return v ? atoi(v) : 0; }();
+  waves = (env_waves == 4 || env_waves == 8) ? env_waves : (n > 8 ? 8 : 4);
+  if (gram_rows_per_mfma(n) * 4 > GRAM_TILE_ROWS / waves) waves = 4;           // (n <= 4: 64 rows per MFMA round)
+  const size_t slot = (size_t)n * DMA_COLB;
+  ring = env_ring >= 2 ? env_ring : 2;
+  if (!env_ring)
+    while (ring < 8 && (size_t)(ring + 1) * slot + DMA_COLB <= 38 * 1024) ring++;   // narrow tables: deeper
+  lds = std::max((size_t)ring * slot + DMA_COLB, sizeof(double) * waves * GRAM_ACC_LEN);
+  wgs_per_cu = env_wgs > 0 ? env_wgs : (int)std::min<size_t>(4, (160 * 1024) / lds);
+  if (wgs_per_cu < 1) wgs_per_cu = 1;
+}
+
+template <int N>
+static hipError_t launch_dma_n(const NumCols &cols, uint64_t nfull, int grid, int waves, size_t lds, int ring,
+                               double *partials, hipStream_t stream) {
+  hipError_t e;
+  if (waves == 8) {
+    if constexpr (gram_rows_per_mfma(N) * 4 <= GRAM_TILE_ROWS / 8) {
+      e = hipFuncSetAttribute((const void *)gram_dma_kernel<N, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((gram_dma_kernel<N, 8>), dim3(grid), dim3(512), lds, stream, cols, nfull, partials, ring);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  }
+  e = hipFuncSetAttribute((const void *)gram_dma_kernel<N, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((gram_dma_kernel<N, 4>), dim3(grid), dim3(256), lds, stream, cols, nfull, partials, ring);
+  return hipGetLastError();
+}
+
 // acc[i] += sum over workgroups of partials[i][wg], fixed tree order: bitwise reproducible.
 __global__ __launch_bounds__(256) void gram_fold_kernel(const double *__restrict__ partials,
                                                         int nwg, double *__restrict__ acc) {
@@ -276,13 +474,13 @@ hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partia
   bool aligned = true;
   for (int k = 0; k < N; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(cols.p[k]) & 15) == 0);
   if (aligned && mask)
-    hipLaunchKernelGGL((gram_kernel<N, true, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+    hipLaunchKernelGGL((gram_kernel<N, true, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
   else if (aligned)
-    hipLaunchKernelGGL((gram_kernel<N, true, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+    hipLaunchKernelGGL((gram_kernel<N, true, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
   else if (mask)
-    hipLaunchKernelGGL((gram_kernel<N, false, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+    hipLaunchKernelGGL((gram_kernel<N, false, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
   else
-    hipLaunchKernelGGL((gram_kernel<N, false, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask);
+    hipLaunchKernelGGL((gram_kernel<N, false, false>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
   return hipGetLastError();
 }
 
@@ -359,8 +557,42 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
   }
   NumCols rest = cols;
   for (int k = 0; k < n; k++) rest.p[k] = cols.p[k] + head;
-  const uint64_t rrows = rows - head;
+  uint64_t rrows = rows - head;
   if (rrows == 0) return ev1 ? hipEventRecord(ev1, stream) : hipSuccess;
+  // COFACTOR_GRAM_DMA=1: whole tiles of aligned, unfiltered columns through the LDS-DMA variant
+  // (measured equal to gram_kernel, 13.4 vs 13.5 ms per 1e9 rows at n = 20: off by default)
+  const char *dma_env = getenv("COFACTOR_GRAM_DMA");
+  const int use_dma = dma_env ? atoi(dma_env) : 0;
+  if (use_dma && !mask && rrows >= 64 * (uint64_t)GRAM_TILE_ROWS) {
+    bool aligned = true;
+    for (int k = 0; k < n; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(rest.p[k]) & 15) == 0);
+    if (aligned) {
+      const uint64_t nfull = rrows / GRAM_TILE_ROWS;
+      int waves, ring, wgs;
+      size_t lds;
+      gram_dma_shape(n, waves, ring, wgs, lds);
+      static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+      int dgrid = std::min(grid, wgs * cus);
+      if ((uint64_t)dgrid > nfull) dgrid = (int)nfull;
+      e = hipErrorInvalidValue;
+      switch (n) {
+#define CASE(N) case N: e = launch_dma_n<N>(rest, nfull, dgrid, waves, lds, ring, partials, stream); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+        CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
+#undef CASE
+        default: break;
+      }
+      if (e != hipSuccess) return e;
+      const uint64_t done = nfull * GRAM_TILE_ROWS;
+      if (done == rrows) {
+        if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
+        return launch_gram_fold(partials, dgrid, acc, stream);
+      }
+      if ((e = launch_gram_fold(partials, dgrid, acc, stream)) != hipSuccess) return e;
+      for (int k = 0; k < n; k++) rest.p[k] += done;
+      rrows -= done;
+    }
+  }
   const uint64_t ntiles = (rrows + GRAM_TILE_ROWS - 1) / GRAM_TILE_ROWS;
   if ((uint64_t)grid > ntiles) grid = (int)ntiles;
   if ((e = launch_gram_kernel(rest, n, rrows, grid, partials, mask ? mask + head : nullptr, stream)) != hipSuccess) return e;
@@ -427,37 +659,43 @@ hipError_t launch_dense_import(const double *in, int n, int kind, double *acc, u
 }
 
 // ---- calibration: what a plain streaming kernel reaches on this GPU (bench.py's second roofline) ---
-// float4 per lane, grid-stride, non-temporal, the access shape of gram_kernel's fetch.
+// float4 per lane, non-temporal, four loads in flight per lane, every workgroup walking its own
+// contiguous range, 16 workgroups per CU: the fastest of the shapes tests/tools/read_probe.hip
+// sweeps (read-only: 7.0 TB/s; the grid-stride shape at 4 workgroups per CU that this used to be:
+// 5.7 TB/s).
 __global__ __launch_bounds__(256) void calib_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
                                                          uint64_t n4) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-    const f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+  const uint64_t per = (n4 / gridDim.x) / 1024 * 1024;
+  uint64_t i = (uint64_t)blockIdx.x * per + threadIdx.x;
+  const uint64_t end = (uint64_t)blockIdx.x * per + per;
+  for (; i < end; i += 1024) {
+    const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256);
+    const f32x4 c = __builtin_nontemporal_load(src + i + 512), d = __builtin_nontemporal_load(src + i + 768);
     __builtin_nontemporal_store(a, dst + i);
-    __builtin_nontemporal_store(b, dst + i + stride);
-    __builtin_nontemporal_store(c, dst + i + 2 * stride);
-    __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    __builtin_nontemporal_store(b, dst + i + 256);
+    __builtin_nontemporal_store(c, dst + i + 512);
+    __builtin_nontemporal_store(d, dst + i + 768);
   }
-  for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 __global__ __launch_bounds__(256) void calib_read_kernel(const f32x4 *__restrict__ src, float *__restrict__ out,
                                                          uint64_t n4) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t per = (n4 / gridDim.x) / 1024 * 1024;
+  uint64_t i = (uint64_t)blockIdx.x * per + threadIdx.x;
+  const uint64_t end = (uint64_t)blockIdx.x * per + per;
   f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
+  for (; i < end; i += 1024) {
     s0 += __builtin_nontemporal_load(src + i);
-    s1 += __builtin_nontemporal_load(src + i + stride);
-    s2 += __builtin_nontemporal_load(src + i + 2 * stride);
-    s3 += __builtin_nontemporal_load(src + i + 3 * stride);
+    s1 += __builtin_nontemporal_load(src + i + 256);
+    s2 += __builtin_nontemporal_load(src + i + 512);
+    s3 += __builtin_nontemporal_load(src + i + 768);
   }
-  for (; i < n4; i += stride) s0 += __builtin_nontemporal_load(src + i);
   const f32x4 s = (s0 + s1) + (s2 + s3);
   const float v = (s[0] + s[1]) + (s[2] + s[3]);
   if (v == 12345.678f) out[0] = v;                 // keeps the loads alive; practically never true
 }
+
+// bytes actually moved by one launch (whole 16-KiB steps of every workgroup's range)
+uint64_t calibration_bytes(uint64_t bytes, int grid) { return ((bytes / 16) / grid) / 1024 * 1024 * (uint64_t)grid * 16; }
 
 hipError_t launch_calibration(const void *src, void *dst, uint64_t bytes, int grid, bool copy, hipStream_t stream) {
   const uint64_t n4 = bytes / 16;

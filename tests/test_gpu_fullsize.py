@@ -124,6 +124,31 @@ def test_10_10_thousand_keys_per_column_exact(ctx):
             q += 1
 
 
+@pytest.mark.parametrize("n", [1, 4, 7, 12, 13, 20])
+def test_lds_dma_variant_of_the_dense_kernel_is_exact(monkeypatch, n):
+    """COFACTOR_GRAM_DMA=1 sends whole tiles through gram_dma_kernel (tiles fetched by LDS-DMA, 4 or 8
+    waves per tile), the tail through gram_kernel: same integer-valued table, same exact sums."""
+    import torch
+    monkeypatch.setenv("COFACTOR_GRAM_DMA", "1")
+    c = cofactor_hip.Context(0)
+    rows = 3_000_000 + 77
+    g = torch.Generator(device="cuda").manual_seed(300 + n)
+    ints = [torch.randint(0, 8, (rows,), generator=g, device="cuda", dtype=torch.int32) for _ in range(n)]
+    cols = [x.float() for x in ints]
+    torch.cuda.synchronize()
+    agg = c.aggregate(n, 0)
+    agg.update_device(cols, [])
+    got = blob_to_dict(agg.finalize())
+    agg.close(); c.close()
+    assert got["N"] == rows
+    assert got["lin_agg"] == [float(int(x.sum(dtype=torch.int64))) for x in ints]
+    q = 0
+    for j in range(n):
+        for k in range(j, n):
+            assert got["quad_agg"][q] == float(int((ints[j] * ints[k]).sum(dtype=torch.int64))), (j, k)
+            q += 1
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 7, 8, 10, 12, 13, 16])
 def test_narrow_tables_exact_through_the_tile_ring(ctx, n):
     """Narrow tables run gram_kernel with a ring of several tiles per workgroup and several rows

@@ -1,0 +1,74 @@
+// Read-only streaming of 20 float columns (the fetch of gram_kernel without anything else):
+// which tile shape / depth / grid reaches the single-stream rate of read_probe.hip?
+//   hipcc --offload-arch=gfx950 -O3 tests/tools/cols_probe.hip -o tests/tools/cols_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct Cols { const float *p[20]; };
+
+// TR rows per tile; a wave reads SEG = TR / 4 ... no: wave w reads columns w, w + 4, .. (5 of them),
+// for each the tile's TR rows as TR / 256 loads of 1 KiB (64 lanes x 16 B); D tiles in flight.
+template <int TR, int D>
+__global__ __launch_bounds__(256) void rd(Cols c, uint64_t rows, float *out, int chunked) {
+  constexpr int L = TR / 256;                      // loads per column and tile per lane
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint64_t ntiles = rows / TR, G = gridDim.x;
+  uint64_t t = blockIdx.x, step = G, end = ntiles;
+  if (chunked) { const uint64_t per = (ntiles + G - 1) / G; t = blockIdx.x * per; end = min(t + per, ntiles); step = 1; if (t > end) t = end; }
+  f32x4 ring[D][5 * L];
+  f32x4 acc = {0, 0, 0, 0};
+  auto fetch = [&](f32x4 (&r)[5 * L], uint64_t tt) {
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+      for (int l = 0; l < L; l++)
+        r[i * L + l] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(c.p[wave + 4 * i] + tt * TR + 256 * l) + lane);
+  };
+  if (t < end) {
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(ring[d], min(t + d * step, end - 1));
+    while (t < end) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+#pragma unroll
+        for (int j = 0; j < 5 * L; j++) acc += ring[d][j];
+        fetch(ring[d], min(t + D * step, end - 1));
+        t += step;
+        if (t >= end) break;
+      }
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = 1.f;
+}
+
+template <int TR, int D>
+void run(const Cols &c, uint64_t rows, float *out, int cus) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int chunked = 0; chunked < 2; chunked++)
+    for (int mult : {2, 4, 8, 16}) {
+      const int grid = cus * mult;
+      hipLaunchKernelGGL((rd<TR, D>), dim3(grid), dim3(256), 0, 0, c, rows, out, chunked);
+      (void)hipEventRecord(e0, 0);
+      for (int r = 0; r < 3; r++) hipLaunchKernelGGL((rd<TR, D>), dim3(grid), dim3(256), 0, 0, c, rows, out, chunked);
+      (void)hipEventRecord(e1, 0);
+      (void)hipEventSynchronize(e1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("TR=%4d D=%d chunked=%d wg/cu=%2d  %.0f GB/s\n", TR, D, chunked, mult, 3.0 * rows * 80 / (ms * 1e-3) / 1e9);
+    }
+}
+
+int main() {
+  const uint64_t rows = 400000000ull;              // 20 x 1.6 GB = 32 GB
+  Cols c;
+  for (int k = 0; k < 20; k++) { (void)hipMalloc((void **)&c.p[k], rows * 4); (void)hipMemset((void *)c.p[k], 0x3c, rows * 4); }
+  float *out; (void)hipMalloc((void **)&out, 4);
+  hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount;
+  run<256, 1>(c, rows, out, cus); run<256, 2>(c, rows, out, cus); run<256, 4>(c, rows, out, cus);
+  run<512, 1>(c, rows, out, cus); run<512, 2>(c, rows, out, cus);
+  run<1024, 1>(c, rows, out, cus); run<1024, 2>(c, rows, out, cus);
+  return 0;
+}
