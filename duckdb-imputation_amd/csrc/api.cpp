@@ -414,6 +414,10 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
     const uint64_t p_from = mfma_pairs ? body : 0;
     if (body) {
       const int grid = fused2_grid(ctx->cus, ctx->gram_grid, body);
+      const int sub_grid = !mfma_sums ? grid
+          : fused2_grid(ctx->cus, ctx->gram_grid, body,
+                        fused2_sub_wgs_per_cu((L.n + groups_n - 1) / groups_n, (L.m + groups_m - 1) / groups_m,
+                                              pmask != nullptr, L, ctx->lds_max));
       if (mfma_pairs) {                            // pair tables, key counts, diagonal cells
         cofactor_status s = ensure_pair_slabs(ctx, fused_slab_bytes(Lp, grid));
         if (s != COFACTOR_OK) return s;
@@ -427,7 +431,7 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
           for (int c = 0; c < mg; c++) idx[c] = c0 + c;
           for (int gn = 0, k0 = 0; gn < groups_n; gn++) {
             const int ng = L.n / groups_n + (gn < L.n % groups_n ? 1 : 0);
-            HIP_TRY(launch_fused2_sub(pn, pc, body, L, a->D, k0, ng, idx, mg, /*do_cnt=*/gn == 0 && !mfma_pairs, grid,
+            HIP_TRY(launch_fused2_sub(pn, pc, body, L, a->D, k0, ng, idx, mg, /*do_cnt=*/gn == 0 && !mfma_pairs, sub_grid,
                                       ctx->lds_max, pmask, st));
             k0 += ng;
           }
@@ -614,7 +618,8 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       ctx->fused_ev.emplace_back(e0, e1);
     }
     const int grid = v1 ? fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows)
-                        : fused2_grid(ctx->cus, ctx->gram_grid, main_rows);
+                        : fused2_grid(ctx->cus, ctx->gram_grid, main_rows,
+                                      fused2_wgs_per_cu(a->L, mask != nullptr, ctx->lds_max));
     {
       cofactor_status s = ensure_pair_slabs(ctx, fused_slab_bytes(a->L, grid));
       if (s != COFACTOR_OK) return s;

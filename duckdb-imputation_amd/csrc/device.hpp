@@ -230,7 +230,10 @@ bool fused2_sub_fits(int n_sub, int m_sub, bool masked, const CatLayout &L, size
 hipError_t launch_fused2_sub(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
                              const CatDevice &D, int k0, int n_sub, const int *cat_idx, int m_sub, bool do_cnt,
                              int grid, size_t lds_limit, const uint8_t *mask, hipStream_t stream);
-int fused2_grid(int cus, int partials_cap_wgs, uint64_t rows);
+int fused2_grid(int cus, int partials_cap_wgs, uint64_t rows, int wgs_per_cu = 1);
+// workgroups per CU the kernel runs with for this shape (2 where there are no pair accumulators)
+int fused2_wgs_per_cu(const CatLayout &L, bool masked, size_t lds_limit);
+int fused2_sub_wgs_per_cu(int n_sub, int m_sub, bool masked, const CatLayout &L, size_t lds_limit);
 // rows one launch may take: the int32 pair accumulators of a wave hold 2^31 / 4096 rows
 inline uint64_t fused2_max_rows(int grid) { return (uint64_t)grid * 8000ull * FUSED_TILE_ROWS; }
 constexpr int FUSED2_SKIP_UNIT = 64;    // rows per entry of the optimistic pass's skip list

@@ -25,6 +25,9 @@
 //   * fp32 chains are folded into fp64 (LDS table for the per-key sums, registers for the Gram)
 //     before they can lose bits; pair counts leave through a per-workgroup slab and
 //     fused_pairs_fold2_kernel.
+#include <cstdio>
+#include <cstdlib>
+
 #include "device.hpp"
 
 namespace cofactor {
@@ -667,15 +670,35 @@ F2Carve f2_carve(const CatLayout &L, const F2Shape &sh, bool masked, int ring) {
   return c;
 }
 
-// deepest ring that fits: at least 3 slots (2 tiles in flight), at most 8
-int f2_ring(const CatLayout &L, const F2Shape &sh, bool masked, size_t lds_limit) {
+// Workgroups per CU: the pair accumulators fill a wave's whole register file (one workgroup per
+// CU); the modes without pair tables need at most 256 registers per wave and run two workgroups
+// per CU — one wave per SIMD hides no latency at all.  COFACTOR_F2_WGS overrides (experiments).
+int f2_wgs(const F2Shape &sh) {
+  if (sh.mode & F2_PAIRS) return 1;
+  const char *v = getenv("COFACTOR_F2_WGS");
+  const int w = v ? atoi(v) : 2;
+  return w < 1 ? 1 : (w > 3 ? 3 : w);
+}
+
+// deepest ring that fits `wgs` workgroups into the CU's LDS: at most 8 slots, at least 3 (2 tiles
+// in flight) for a lone workgroup, 2 when several share the CU (their loads overlap each other)
+int f2_ring_for(const CatLayout &L, const F2Shape &sh, bool masked, size_t lds_limit, int wgs) {
   int best = 0;
-  for (int r = 3; r <= 8; r++) {
+  for (int r = wgs > 1 ? 2 : 3; r <= 8; r++) {
     const F2Carve c = f2_carve(L, sh, masked, r);
     const int cpw = (L.n + L.m + (masked ? 1 : 0) + 3) / 4;
-    if ((size_t)c.total <= lds_limit && (r - 2) * cpw <= 48) best = r;
+    if ((size_t)c.total * wgs <= lds_limit && (r - 2) * cpw <= 48) best = r;
   }
   return best;
+}
+// ring depth and workgroups per CU of a launch
+int f2_ring(const CatLayout &L, const F2Shape &sh, bool masked, size_t lds_limit, int *wgs_out = nullptr) {
+  for (int wgs = f2_wgs(sh); wgs >= 1; wgs--) {
+    const int r = f2_ring_for(L, sh, masked, lds_limit, wgs);
+    if (r >= 2) { if (wgs_out) *wgs_out = wgs; return r; }
+  }
+  if (wgs_out) *wgs_out = 1;
+  return 0;
 }
 
 template <int NBLK, int NBB, int M, int MODE>
@@ -714,15 +737,23 @@ bool fused2_applicable(const CatLayout &L, const int32_t *nkeys, bool masked, si
     if (nkeys[c] > 16 || L.kc[c] != 16) return false;
   F2Shape sh;
   if (!f2_shape(L, sh)) return false;
-  return f2_ring(L, sh, masked, lds_limit) >= 3;
+  return f2_ring(L, sh, masked, lds_limit) >= 2;
 }
 
-int fused2_grid(int cus, int partials_cap_wgs, uint64_t rows) {
-  int grid = cus;                                             // the kernel claims a CU's LDS: one workgroup each
+int fused2_grid(int cus, int partials_cap_wgs, uint64_t rows, int wgs_per_cu) {
+  int grid = cus * (wgs_per_cu < 1 ? 1 : wgs_per_cu);         // the kernel claims 1 / wgs_per_cu of a CU's LDS
   if (grid > partials_cap_wgs) grid = partials_cap_wgs;
   const uint64_t ntiles = rows / TR;
   if ((uint64_t)grid > ntiles) grid = (int)ntiles;
   return grid;
+}
+
+int fused2_wgs_per_cu(const CatLayout &L, bool masked, size_t lds_limit) {
+  F2Shape sh;
+  int wgs = 1;
+  if (!f2_shape(L, sh)) return 1;
+  (void)f2_ring(L, sh, masked, lds_limit, &wgs);
+  return wgs;
 }
 
 hipError_t launch_fused2(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
@@ -734,7 +765,7 @@ hipError_t launch_fused2(const NumCols &num, const CatCols &cat, uint64_t rows, 
   if (!f2_shape(L, sh)) return hipErrorInvalidValue;
   const bool masked = mask != nullptr;
   const int ring = f2_ring(L, sh, masked, lds_limit);
-  if (ring < 3) return hipErrorInvalidValue;
+  if (ring < 2) return hipErrorInvalidValue;
   const F2Carve cv = f2_carve(L, sh, masked, ring);
   hipError_t e = hipErrorInvalidValue;
   if (ev0 && (e = hipEventRecord(ev0, stream)) != hipSuccess) return e;
@@ -790,11 +821,19 @@ bool sub_shape(int n_sub, int m_sub, F2Shape &sh) {
 }
 }  // namespace
 
+int fused2_sub_wgs_per_cu(int n_sub, int m_sub, bool masked, const CatLayout &L, size_t lds_limit) {
+  F2Shape sh;
+  int wgs = 1;
+  if (!sub_shape(n_sub, m_sub, sh)) return 1;
+  (void)f2_ring(sub_layout(L, n_sub, nullptr, m_sub), sh, masked, lds_limit, &wgs);
+  return wgs;
+}
+
 bool fused2_sub_fits(int n_sub, int m_sub, bool masked, const CatLayout &L, size_t lds_limit) {
   F2Shape sh;
   if (!sub_shape(n_sub, m_sub, sh)) return false;
   const CatLayout S = sub_layout(L, n_sub, nullptr, m_sub);
-  return f2_ring(S, sh, masked, lds_limit) >= 3;
+  return f2_ring(S, sh, masked, lds_limit) >= 2;
 }
 
 hipError_t launch_fused2_sub(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
@@ -806,7 +845,7 @@ hipError_t launch_fused2_sub(const NumCols &num, const CatCols &cat, uint64_t ro
   const CatLayout S = sub_layout(L, n_sub, cat_idx, m_sub);
   const bool masked = mask != nullptr;
   const int ring = f2_ring(S, sh, masked, lds_limit);
-  if (ring < 3) return hipErrorInvalidValue;
+  if (ring < 2) return hipErrorInvalidValue;
   const F2Carve cv = f2_carve(S, sh, masked, ring);
   NumCols ns{};
   CatCols cs{};

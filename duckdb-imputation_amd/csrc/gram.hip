@@ -210,6 +210,21 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
     while (t < tend) {
 #pragma unroll
       for (int r = 0; r < DEPTH; r++) {           // tile t sits in ring slot r
+#ifdef COFACTOR_DEV_ABLATE
+        // 1: no MFMA loop; 2: no park either (barriers stay); 3: bare loads (no park, no barriers)
+        if (ablate >= 2) {
+          float sink = 0.f;
+#pragma unroll
+          for (int i = 0; i < LD; i++) sink += pre[r][i].x + pre[r][i].y + pre[r][i].z + pre[r][i].w;
+          if (sink == 12345.678f) dl += 1.0;
+          if (ablate == 2) __syncthreads();
+          fetch(pre[r], pmask[r], min(t + DEPTH * tstep, tend - 1));
+          if (ablate == 2) __syncthreads();
+          t += tstep;
+          if (t >= tend) break;
+          continue;
+        }
+#endif
         park(pre[r], pmask[r]);
         __syncthreads();
         fetch(pre[r], pmask[r], min(t + DEPTH * tstep, tend - 1));   // flies under DEPTH tiles of MFMAs

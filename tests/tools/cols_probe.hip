@@ -9,7 +9,7 @@ struct Cols { const float *p[20]; };
 
 // TR rows per tile; a wave reads SEG = TR / 4 ... no: wave w reads columns w, w + 4, .. (5 of them),
 // for each the tile's TR rows as TR / 256 loads of 1 KiB (64 lanes x 16 B); D tiles in flight.
-template <int TR, int D>
+template <int TR, int D, bool BAR>
 __global__ __launch_bounds__(256) void rd(Cols c, uint64_t rows, float *out, int chunked) {
   constexpr int L = TR / 256;                      // loads per column and tile per lane
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256) void rd(Cols c, uint64_t rows, float *out, int
       for (int d = 0; d < D; d++) {
 #pragma unroll
         for (int j = 0; j < 5 * L; j++) acc += ring[d][j];
+        if (BAR) __syncthreads();                 // the whole workgroup has its part of tile t (as gram_kernel's park)
         fetch(ring[d], min(t + D * step, end - 1));
+        if (BAR) __syncthreads();
         t += step;
         if (t >= end) break;
       }
@@ -42,21 +44,21 @@ __global__ __launch_bounds__(256) void rd(Cols c, uint64_t rows, float *out, int
   if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = 1.f;
 }
 
-template <int TR, int D>
+template <int TR, int D, bool BAR>
 void run(const Cols &c, uint64_t rows, float *out, int cus) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int chunked = 0; chunked < 2; chunked++)
     for (int mult : {2, 4, 8, 16}) {
       const int grid = cus * mult;
-      hipLaunchKernelGGL((rd<TR, D>), dim3(grid), dim3(256), 0, 0, c, rows, out, chunked);
+      hipLaunchKernelGGL((rd<TR, D, BAR>), dim3(grid), dim3(256), 0, 0, c, rows, out, chunked);
       (void)hipEventRecord(e0, 0);
-      for (int r = 0; r < 3; r++) hipLaunchKernelGGL((rd<TR, D>), dim3(grid), dim3(256), 0, 0, c, rows, out, chunked);
+      for (int r = 0; r < 3; r++) hipLaunchKernelGGL((rd<TR, D, BAR>), dim3(grid), dim3(256), 0, 0, c, rows, out, chunked);
       (void)hipEventRecord(e1, 0);
       (void)hipEventSynchronize(e1);
       float ms = 0;
       (void)hipEventElapsedTime(&ms, e0, e1);
-      printf("TR=%4d D=%d chunked=%d wg/cu=%2d  %.0f GB/s\n", TR, D, chunked, mult, 3.0 * rows * 80 / (ms * 1e-3) / 1e9);
+      printf("bar=%d TR=%4d D=%d chunked=%d wg/cu=%2d  %.0f GB/s\n", (int)BAR, TR, D, chunked, mult, 3.0 * rows * 80 / (ms * 1e-3) / 1e9);
     }
 }
 
@@ -67,8 +69,6 @@ int main() {
   float *out; (void)hipMalloc((void **)&out, 4);
   hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount;
-  run<256, 1>(c, rows, out, cus); run<256, 2>(c, rows, out, cus); run<256, 4>(c, rows, out, cus);
-  run<512, 1>(c, rows, out, cus); run<512, 2>(c, rows, out, cus);
-  run<1024, 1>(c, rows, out, cus); run<1024, 2>(c, rows, out, cus);
+  run<256, 2, false>(c, rows, out, cus); run<256, 2, true>(c, rows, out, cus); run<256, 4, true>(c, rows, out, cus);
   return 0;
 }

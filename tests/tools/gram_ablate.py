@@ -9,10 +9,10 @@ rows, n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 500_000_000, 20
 g = torch.Generator(device="cuda").manual_seed(1)
 num = [torch.rand(rows, generator=g, device="cuda") for _ in range(n)]
 torch.cuda.synchronize()
-for wgs in (4, 8):
+for wgs in (4,):
     os.environ["COFACTOR_GRAM_WGS_PER_CU"] = str(wgs)
     ctx = cofactor_hip.Context(0)
-    for mask, label in [(0, "full"), (1, "loads + LDS park, no MFMA"), (2, "loads only")]:
+    for mask, label in [(0, "full"), (1, "loads + park + barriers, no MFMA"), (2, "loads + barriers"), (3, "bare loads")]:
         os.environ["COFACTOR_GRAM_ABLATE"] = str(mask)
         agg = ctx.aggregate(n, 0)
         agg.update_device(num, []); ctx.synchronize()
