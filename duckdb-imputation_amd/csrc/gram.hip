@@ -75,20 +75,27 @@ __host__ __device__ constexpr int gram_ring_depth(int n) {
 // (experiment knob: COFACTOR_GRAM_CHUNKED)
 static int g_gram_chunked = [] { const char *v = getenv("COFACTOR_GRAM_CHUNKED"); return v ? atoi(v) : 0; }();
 
-template <int N, bool ALIGNED, bool MASKED>
+// T16 (13 <= N <= 16): the whole 16 x 16 matrix of a row as ONE v_mfma_f32_16x16x4_f32 per four rows
+// — lane (column i = lane & 15, row kq = lane >> 4 of the group) feeds the same register as A and
+// B — instead of ten 4 x 4 block pairs on v_mfma_f32_4x4x1: one ds_read_b32 + one MFMA + one add
+// per four rows where the block scheme needs two ds_read_b128 + four MFMAs + two packed adds.
+// At 13..16 columns the block scheme sits on its per-row instruction floor below the HBM rate;
+// both triangles come out (the lower one is dropped in the fold).
+template <int N, bool ALIGNED, bool MASKED, bool T16 = false>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64_t rows,
                                                             double *__restrict__ partials,
                                                             const uint8_t *__restrict__ mask_arg, int chunked) {
   const uint8_t *__restrict__ mask = MASKED ? mask_arg : nullptr;   // unfiltered variant: no filter bytes are read
   constexpr int NB = (N + 3) / 4;
   constexpr int NPAIR = NB * (NB + 1) / 2;
-  constexpr int NBC = 4 * NB;                     // data columns incl. zero padding to 4*NB
+  constexpr int NBC = T16 ? 16 : 4 * NB;          // data columns incl. zero padding to 4*NB (T16: to 16)
   constexpr int CS = GRAM_COL_STRIDE;
   constexpr int LD = (N * 64 + GRAM_THREADS - 1) / GRAM_THREADS;  // float4 loads / thread / tile
   constexpr int RPM = gram_rows_per_mfma(N);
   constexpr int DEPTH = gram_ring_depth(N);
   // columns [0,N) data, [N,NBC) zero padding, column NBC all-zero (operand of unused blocks)
-  constexpr int TILE_FLOATS = (NBC + 1) * CS > 8 * GRAM_ACC_LEN ? (NBC + 1) * CS : 8 * GRAM_ACC_LEN;
+  constexpr int SCRATCH_FLOATS = (T16 ? 10 : 8) * GRAM_ACC_LEN;   // wave fold: 4 images of doubles (T16: + the result)
+  constexpr int TILE_FLOATS = (NBC + 1) * CS > SCRATCH_FLOATS ? (NBC + 1) * CS : SCRATCH_FLOATS;
   __shared__ __attribute__((aligned(16))) float tile[TILE_FLOATS];  // also the wave-fold scratch
 
   const int tid = threadIdx.x;
@@ -164,8 +171,32 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   // steps over the RPM groups of each round
   const float *pa = tile + colA * CS + wave * 64 + 4 * rsub;
   const float *pb = tile + colB * CS + wave * 64 + 4 * rsub;
+  // T16: this lane's operand of row group g is tile[column lane & 15][wave's row 4 g + (lane >> 4)]
+  const float *p16 = tile + (lane & 15) * CS + wave * 64 + (lane >> 4);
+  float ls16 = 0.f;
   int since_flush = 0;
   auto crunch = [&]() {
+    if constexpr (T16) {
+      static_assert(!T16 || (N > 12 && N <= 16), "one 16 x 16 tile");
+#pragma unroll
+      for (int g = 0; g < 16; g += 4) {           // four independent chains
+        const float x0 = p16[4 * g], x1 = p16[4 * g + 4], x2 = p16[4 * g + 8], x3 = p16[4 * g + 12];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, x0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, x1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x2, x2, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x3, x3, acc3, 0, 0, 0);
+        ls16 += (x0 + x1) + (x2 + x3);
+      }
+      // every tile: 4 chains x 4 MFMAs x 4 rows = 64 fp32 adds per cell
+      dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
+      dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
+      dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
+      dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
+      dl += (double)ls16;
+      acc0 = acc1 = acc2 = acc3 = f32x4{0, 0, 0, 0};
+      ls16 = 0.f;
+      return;
+    }
     const f32x4 *va = reinterpret_cast<const f32x4 *>(pa);
     const f32x4 *vb = reinterpret_cast<const f32x4 *>(pb);
 #pragma unroll 4
@@ -266,6 +297,29 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
   mine[3 * 64 + lane] = dq3;
   mine[4 * 64 + lane] = dl;
   __syncthreads();
+  if constexpr (T16) {
+    // register r of lane l holds cell (row 4 (l >> 4) + r, column l & 15); lin[c] is spread over the
+    // four lanes c, 16 + c, 32 + c, 48 + c.  Into the image layout of device.hpp (fixed order).
+    auto over_waves = [&](int j) { return ((red[j] + red[GRAM_ACC_LEN + j]) + red[2 * GRAM_ACC_LEN + j]) + red[3 * GRAM_ACC_LEN + j]; };
+    static_assert(!T16 || sizeof(double) * 5 * GRAM_ACC_LEN <= sizeof(float) * TILE_FLOATS, "image scratch must fit the tile");
+    double *img = red + 4 * GRAM_ACC_LEN;
+    for (int i = tid; i < GRAM_ACC_LEN; i += GRAM_THREADS) img[i] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < 16 * 16 + 16; e += GRAM_THREADS) {
+      if (e < 256) {
+        const int j = e >> 4, k = e & 15;
+        if (j <= k && k < N) img[gram_quad_pos(j, k, N)] = over_waves((j & 3) * 64 + 16 * (j >> 2) + k);
+      } else {
+        const int c = e - 256;
+        if (c < N)
+          img[gram_lin_pos(c, N)] = (over_waves(4 * 64 + c) + over_waves(4 * 64 + 16 + c)) +
+                                    (over_waves(4 * 64 + 32 + c) + over_waves(4 * 64 + 48 + c));
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < GRAM_ACC_LEN; i += GRAM_THREADS) partials[(uint64_t)i * gridDim.x + blockIdx.x] = img[i];
+    return;
+  }
   for (int i = tid; i < GRAM_ACC_LEN; i += GRAM_THREADS) {
     const int ln = i & 63;
     double v = 0;
@@ -488,6 +542,22 @@ hipError_t launch_n(const NumCols &cols, uint64_t rows, int grid, double *partia
                     const uint8_t *mask, hipStream_t stream) {
   bool aligned = true;
   for (int k = 0; k < N; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(cols.p[k]) & 15) == 0);
+  // (up to 12 columns the block scheme packs 2..16 rows into one MFMA and wins: measured 5..12)
+  constexpr bool T16 = N > 12 && N <= 16;
+  static const bool no16 = [] { const char *v = getenv("COFACTOR_GRAM_NO16"); return v && *v == '1'; }();
+  if (T16 && !no16) {
+    if constexpr (T16) {
+      if (aligned && mask)
+        hipLaunchKernelGGL((gram_kernel<N, true, true, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
+      else if (aligned)
+        hipLaunchKernelGGL((gram_kernel<N, true, false, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
+      else if (mask)
+        hipLaunchKernelGGL((gram_kernel<N, false, true, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
+      else
+        hipLaunchKernelGGL((gram_kernel<N, false, false, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
+    }
+    return hipGetLastError();
+  }
   if (aligned && mask)
     hipLaunchKernelGGL((gram_kernel<N, true, true>), dim3(grid), dim3(GRAM_THREADS), 0, stream, cols, rows, partials, mask, g_gram_chunked);
   else if (aligned)
