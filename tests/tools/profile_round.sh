@@ -15,7 +15,7 @@ run() { # name, extra bench args...   (KEY / KROWS: the traffic.json entry this 
   # condensed on the box (the raw CSVs are large): summaries go to gpurun_out/profiles_<tag>/
   mkdir -p $R/gpurun_out/profiles_${TAG}
   PROFILES_OUT=$R/gpurun_out/profiles_${TAG} python3 $R/profiles/summarize.py ${TAG} $R/gpurun_out/${TAG}_${name}_trace $R/gpurun_out/${TAG}_${name}_fetch $R/gpurun_out/${TAG}_${name}_write ${name} "$KEY" "$KROWS" > /dev/null
-  tail -1 $R/gpurun_out/${TAG}_${name}_trace.log > $R/gpurun_out/profiles_${TAG}/${TAG}_bench_${name}.log
+  grep '^{' $R/gpurun_out/${TAG}_${name}_trace.log | tail -1 > $R/gpurun_out/profiles_${TAG}/${TAG}_bench_${name}.log
   rm -rf $R/gpurun_out/${TAG}_${name}_trace $R/gpurun_out/${TAG}_${name}_fetch $R/gpurun_out/${TAG}_${name}_write $R/gpurun_out/${TAG}_${name}_trace.log
   echo "profiled $name"
 }
@@ -26,6 +26,7 @@ if [ "$2" = "rest" ]; then
 fi
 KEY=gram_kernel_20_0 KROWS=1000000000 run 20_0 && KEY=fused_kernel_10_10 KROWS=100000000 run 10_10 --total-rows 1e8 --num-cols 10 --cat-cols 10 && KEY=fused_kernel_nb_10_10 KROWS=100000000 run nb_10_10 --total-rows 1e8 --num-cols 10 --cat-cols 10 --nb \
   && KEY="" run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && run 20_20 --total-rows 5e7 --num-cols 20 --cat-cols 20 \
+  && run 20_10 --total-rows 5e7 --num-cols 20 --cat-cols 10 && run 16_0 --total-rows 1e9 --num-cols 16 \
   && run 10_10_k1000 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 1000 \
   && sh $R/tests/tools/sq_counters.sh ${TAG}_gram_20_0 gram_kernel \
   && sh $R/tests/tools/sq_counters.sh ${TAG}_fused_10_10 fused_kernel --total-rows 1e8 --num-cols 10 --cat-cols 10 \
