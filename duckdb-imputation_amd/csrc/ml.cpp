@@ -201,20 +201,28 @@ namespace {
 
 // v = Sigma * theta: the one product both the gradient and the objective need (the reference
 // forms it twice per iteration, compute_gradient regression.cpp:27-46 and compute_error :48-77).
-// Four partial sums per row so the loop vectorises.
+// Eight partial sums per row so the loop vectorises; compiled for AVX-512 / AVX2 as well and
+// picked at load time (the descent calls this up to 10 000 times on a p x p matrix: it IS the
+// training time).  No contraction into FMAs: every clone rounds the same way.
+#if defined(__x86_64__) && defined(__linux__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+void sigma_times_raw(size_t p, const double *__restrict__ s, const double *__restrict__ th, double *__restrict__ v) {
+#pragma clang fp contract(off)
+  for (size_t i = 0; i < p; i++) {
+    const double *row = s + i * p;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t j = 0;
+    for (; j + 8 <= p; j += 8)
+      for (int u = 0; u < 8; u++) a[u] += row[j + u] * th[j + u];
+    double tail = 0;
+    for (; j < p; j++) tail += row[j] * th[j];
+    v[i] = (((a[0] + a[4]) + (a[1] + a[5])) + ((a[2] + a[6]) + (a[3] + a[7]))) + tail;
+  }
+}
 void sigma_times(size_t p, const std::vector<double> &s, const std::vector<double> &th,
                  std::vector<double> &v) {
-  for (size_t i = 0; i < p; i++) {
-    const double *row = &s[i * p];
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    size_t j = 0;
-    for (; j + 4 <= p; j += 4) {
-      a0 += row[j] * th[j]; a1 += row[j + 1] * th[j + 1];
-      a2 += row[j + 2] * th[j + 2]; a3 += row[j + 3] * th[j + 3];
-    }
-    for (; j < p; j++) a0 += row[j] * th[j];
-    v[i] = (a0 + a1) + (a2 + a3);
-  }
+  sigma_times_raw(p, s.data(), th.data(), v.data());
 }
 
 // 1/N * Sigma * theta with the label's entry forced to 0
@@ -283,7 +291,7 @@ bool linreg_train(const ListTriple &t, int label0, float step_size, float lambda
   // the reference keeps the step in a float (regression.cpp:115); so do we, the trajectory of the
   // descent depends on it
   float step = step_size;
-  int it = 1;
+  int it = 1, stalled = 0;
   do {
     upd[0] = g[0];
     gnorm = upd[0] * upd[0];
@@ -319,6 +327,12 @@ bool linreg_train(const ListTriple &t, int label0, float step_size, float lambda
     }
     gnorm = std::sqrt(gnorm);
     if (dnorm < 1e-20 || gnorm / (first_gnorm + 0.001) < 1e-8) break;
+    // The reference's two criteria alone can idle until max_iterations: the objective reaches its
+    // last bit with the gradient ratio a hair above 1e-8 and steps of 1e-19 (seen on uniform
+    // data: 31 useful iterations, 9 969 idle ones).  Three iterations in a row without any
+    // decrease of the objective end the descent; the parameters no longer move by then.
+    stalled = (e < prev_err) ? 0 : stalled + 1;
+    if (stalled >= 3) break;
     gradient(p, label, N, sv, g);   // sv is Sigma * theta of the accepted point
     step = (float)bb_step(step, p, th, pth, g, pg);
     prev_err = e;
