@@ -105,6 +105,14 @@ cofactor_status cofactor_agg_reset(cofactor_agg *agg);
 /* update — Triple::SumNoLift (duckdb_extension/src/triple/sum/sum_no_lift.cpp:53-216) and
  * Triple::sum_to_nb_agg (duckdb_extension/src/triple/sum/sum_to_nb_agg.cpp:39-146).
  *
+ * Cardinalities: any number of distinct keys per column up to 2^27 (the per-key count / sum tables
+ * are dense in the key's code).  A pair table (sum_no_lift.cpp:195-214) is dense, code-indexed,
+ * while it has at most 2^26 cells and all dense pair tables together at most 2^30; beyond that the
+ * pair is kept as a sorted (key1, key2) -> count list in device memory, like the reference's
+ * std::map.  States that hold such lists work with update / combine / finalize / reset; the
+ * dictionary-aligned table exchange, sum_triple into them and the GROUP BY pool return
+ * COFACTOR_ERR_UNSUPPORTED.
+ *
  * Device form: the columns are resident in this context's HBM (d_num[k] -> float[rows],
  * d_cat[c] -> int32[rows]; the pointer arrays themselves are host arrays).  Asynchronous on the
  * context stream: work the caller queued on OTHER streams that writes these columns must have
