@@ -135,19 +135,10 @@ __global__ void tvec_dense_apply_kernel(const double *__restrict__ red, int n, i
 // ---- sum_triple: key lists --------------------------------------------------------------------------
 // pass 0: every key of every lin_cat sub-list into its column's dictionary
 // pass 1: lin_cat values -> cnt, quad_num_cat values -> s, quad_cat values -> p (codes via the dictionaries)
-// LDS_TABLES (pass 1 only): the three tables as doubles in LDS, private to the workgroup, added to
-// the aggregate's tables at the end (lifted rows hammer a handful of cells: global atomics on
-// them serialise).
-template <bool LDS_TABLES>
+// One work item = one sub-list (m + n m + T(m) of them per triple; one entry each for lifted rows,
+// up to #keys for grouped ones).
 __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayout L, CatDevice D, int pass) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  double *l_t = reinterpret_cast<double *>(lds_raw);   // [cnt | s | p]
   const int n = v.n, m = v.m;
-  const int cells = L.n_cnt + L.n_s + L.n_p;
-  if (LDS_TABLES) {
-    for (int i = threadIdx.x; i < cells; i += 256) l_t[i] = 0.0;
-    __syncthreads();
-  }
   const int Tm = v.kind ? 0 : tri_i(m), nm = v.kind ? 0 : n * m;
   const uint64_t per_row = (uint64_t)m + (pass ? nm + Tm : 0);
   const uint64_t total = v.count * per_row;
@@ -162,8 +153,7 @@ __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayo
         else {
           const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], v.lc_key[e]);
           if (code < 0 || code >= L.kc[c]) { D.flags[1] = 1; continue; }
-          if (LDS_TABLES) unsafeAtomicAdd(&l_t[L.cnt_off[c] + code], (double)v.lc_val[e]);
-          else atomicAdd(&D.cnt[L.cnt_off[c] + code], (unsigned long long)(v.lc_val[e] + 0.5f));
+          atomicAdd(&D.cnt[L.cnt_off[c] + code], (unsigned long long)(v.lc_val[e] + 0.5f));
         }
       }
       continue;
@@ -175,8 +165,7 @@ __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayo
       for (uint64_t e = off; e < off + len; e++) {
         const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], v.nc_key[e]);
         if (code < 0 || code >= L.kc[c]) { D.flags[1] = 1; continue; }
-        if (LDS_TABLES) unsafeAtomicAdd(&l_t[L.n_cnt + L.s_off[c] + code * n + k], (double)v.nc_val[e]);
-        else unsafeAtomicAdd(&D.s[L.s_off[c] + (long long)code * n + k], (double)v.nc_val[e]);
+        unsafeAtomicAdd(&D.s[L.s_off[c] + (long long)code * n + k], (double)v.nc_val[e]);
       }
       continue;
     }
@@ -189,20 +178,112 @@ __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayo
         const int k1 = cat_lookup_code(D.ht_slot + L.ht_off[c1], D.ht_code + L.ht_off[c1], L.ht_cap[c1], v.cc_key1[e]);
         const int k2 = cat_lookup_code(D.ht_slot + L.ht_off[c2], D.ht_code + L.ht_off[c2], L.ht_cap[c2], v.cc_key2[e]);
         if (k1 < 0 || k2 < 0 || k1 >= L.kc[c1] || k2 >= L.kc[c2]) { D.flags[1] = 1; continue; }
-        if (LDS_TABLES) unsafeAtomicAdd(&l_t[L.n_cnt + L.n_s + L.p_off[s] + k1 * L.kc[c2] + k2], (double)v.cc_val[e]);
-        else atomicAdd(&D.p[L.p_off[s] + (long long)k1 * L.kc[c2] + k2], (unsigned long long)(v.cc_val[e] + 0.5f));
+        atomicAdd(&D.p[L.p_off[s] + (long long)k1 * L.kc[c2] + k2], (unsigned long long)(v.cc_val[e] + 0.5f));
       }
     }
   }
-  if (LDS_TABLES) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < cells; i += 256) {
-      const double t = l_t[i];
-      if (t == 0.0) continue;
-      if (i < L.n_cnt) atomicAdd(&D.cnt[i], (unsigned long long)(t + 0.5));
-      else if (i < L.n_cnt + L.n_s) unsafeAtomicAdd(&D.s[i - L.n_cnt], t);
-      else atomicAdd(&D.p[i - L.n_cnt - L.n_s], (unsigned long long)(t + 0.5));
+}
+
+// Pass 1 when the three tables (as doubles) and the dictionaries fit LDS: tables private to the
+// workgroup (lifted rows hammer a handful of cells: global atomics on them serialise), added to
+// the aggregate's at the end; dictionaries probed in LDS; FOUR sub-lists in flight per thread —
+// the chain outer entry -> sub-list entry -> key / value -> probe is all dependent loads, and one
+// chain per thread leaves the kernel waiting on memory latency (1.7e9 triples/s at 4_2 before).
+// The three children go one after the other (KIND 0 lin_cat, 1 quad_num_cat, 2 quad_cat), so
+// every loop is over sub-lists of one shape.
+template <int KIND>
+__device__ __forceinline__ bool tvec_child_to_lds(const cofactor_tvec &v, const CatLayout &L, double *l_t,
+                                                  const unsigned long long *l_slot, const int32_t *l_code) {
+  const int n = v.n, m = v.m;
+  const uint64_t *outer = KIND == 0 ? v.lc_outer : (KIND == 1 ? v.nc_outer : v.cc_outer);
+  const uint64_t *sube = KIND == 0 ? v.lc_sub : (KIND == 1 ? v.nc_sub : v.cc_sub);
+  const int32_t *key1 = KIND == 0 ? v.lc_key : (KIND == 1 ? v.nc_key : v.cc_key1);
+  const int32_t *key2 = v.cc_key2;
+  const float *vals = KIND == 0 ? v.lc_val : (KIND == 1 ? v.nc_val : v.cc_val);
+  const int per_row = KIND == 0 ? m : (KIND == 1 ? n * m : tri_i(m));
+  const uint64_t total = v.count * (uint64_t)per_row;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  constexpr int U = 4;
+  bool bad = false;
+  for (uint64_t w0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w0 < total; w0 += U * stride) {
+    int sidx[U];
+    uint64_t off[U], len[U], sub[U], maxlen = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint64_t w = w0 + u * stride;
+      const bool in = w < total;
+      const uint64_t i = in ? w / per_row : 0;
+      sidx[u] = in ? (int)(w - i * per_row) : 0;
+      sub[u] = in ? outer[2 * i] + sidx[u] : 0;
+      len[u] = in ? 1 : 0;                        // (marks the slot; the real length follows)
     }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      off[u] = len[u] ? sube[2 * sub[u]] : 0;
+      len[u] = len[u] ? sube[2 * sub[u] + 1] : 0;
+      maxlen = max(maxlen, len[u]);
+    }
+    for (uint64_t e = 0; e < maxlen; e++) {
+      int32_t ka[U], kb[U];
+      float val[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const bool live = e < len[u];
+        const uint64_t at = off[u] + e;
+        ka[u] = live ? key1[at] : 0;
+        kb[u] = (KIND == 2 && live) ? key2[at] : 0;
+        val[u] = live ? vals[at] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (e < len[u]) {
+          int cell = -1;
+          if (KIND == 0) {
+            const int c = sidx[u];
+            const int code = cat_lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], ka[u]);
+            if (code >= 0 && code < L.kc[c]) cell = L.cnt_off[c] + code;
+          } else if (KIND == 1) {
+            const int k = sidx[u] / m, c = sidx[u] - k * m;
+            const int code = cat_lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], ka[u]);
+            if (code >= 0 && code < L.kc[c]) cell = L.n_cnt + L.s_off[c] + code * n + k;
+          } else {
+            int c1, c2;
+            pair_decode(sidx[u], m, c1, c2);
+            const int k1 = cat_lookup_code(l_slot + L.ht_off[c1], l_code + L.ht_off[c1], L.ht_cap[c1], ka[u]);
+            const int k2 = cat_lookup_code(l_slot + L.ht_off[c2], l_code + L.ht_off[c2], L.ht_cap[c2], kb[u]);
+            if (k1 >= 0 && k2 >= 0 && k1 < L.kc[c1] && k2 < L.kc[c2]) cell = L.n_cnt + L.n_s + L.p_off[sidx[u]] + k1 * L.kc[c2] + k2;
+          }
+          if (cell >= 0) unsafeAtomicAdd(&l_t[cell], (double)val[u]);
+          else bad = true;
+        }
+      }
+    }
+  }
+  return bad;
+}
+
+__global__ __launch_bounds__(256) void tvec_keys_lds_kernel(cofactor_tvec v, CatLayout L, CatDevice D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int cells = L.n_cnt + L.n_s + L.n_p;
+  double *l_t = reinterpret_cast<double *>(lds_raw);                        // [cnt | s | p]
+  unsigned long long *l_slot = reinterpret_cast<unsigned long long *>(l_t + cells);
+  int32_t *l_code = reinterpret_cast<int32_t *>(l_slot + L.n_slots);
+  for (int i = threadIdx.x; i < cells; i += 256) l_t[i] = 0.0;
+  for (int i = threadIdx.x; i < L.n_slots; i += 256) { l_slot[i] = D.ht_slot[i]; l_code[i] = D.ht_code[i]; }
+  __syncthreads();
+  bool bad = tvec_child_to_lds<0>(v, L, l_t, l_slot, l_code);
+  if (!v.kind) {
+    bad = tvec_child_to_lds<1>(v, L, l_t, l_slot, l_code) || bad;
+    bad = tvec_child_to_lds<2>(v, L, l_t, l_slot, l_code) || bad;
+  }
+  if (bad) D.flags[1] = 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < cells; i += 256) {
+    const double t = l_t[i];
+    if (t == 0.0) continue;
+    if (i < L.n_cnt) atomicAdd(&D.cnt[i], (unsigned long long)(t + 0.5));
+    else if (i < L.n_cnt + L.n_s) unsafeAtomicAdd(&D.s[i - L.n_cnt], t);
+    else atomicAdd(&D.p[i - L.n_cnt - L.n_s], (unsigned long long)(t + 0.5));
   }
 }
 
@@ -564,12 +645,12 @@ hipError_t launch_tvec_keys(const cofactor_tvec &v, const CatLayout &L, const Ca
   if (v.count == 0 || v.m == 0) return hipSuccess;
   const int Tm = v.kind ? 0 : tri_i(v.m), nm = v.kind ? 0 : v.n * v.m;
   const uint64_t total = v.count * ((uint64_t)v.m + (pass ? nm + Tm : 0));
-  const size_t lds = (size_t)(L.n_cnt + L.n_s + L.n_p) * 8;
-  if (pass == 1 && lds <= 48 * 1024) {
-    const int grid = (int)std::min<uint64_t>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL((tvec_keys_kernel<true>), dim3(grid), dim3(256), lds, stream, v, L, D, pass);
+  const size_t lds = (size_t)(L.n_cnt + L.n_s + L.n_p) * 8 + (size_t)L.n_slots * 12;
+  if (pass == 1 && lds <= 40 * 1024) {
+    const int grid = (int)std::min<uint64_t>((total + 1023) / 1024, 4096);
+    hipLaunchKernelGGL(tvec_keys_lds_kernel, dim3(grid), dim3(256), lds, stream, v, L, D);
   } else {
-    hipLaunchKernelGGL((tvec_keys_kernel<false>), dim3(grid_for(total)), dim3(256), 0, stream, v, L, D, pass);
+    hipLaunchKernelGGL(tvec_keys_kernel, dim3(grid_for(total)), dim3(256), 0, stream, v, L, D, pass);
   }
   return hipGetLastError();
 }

@@ -11,9 +11,11 @@ from oracle import oracle as orc
 from triple_fmt import blob_to_dict
 ctx = cofactor_hip.Context(0)
 bad = 0
-for (n, m, nb) in [(0, 3, False), (0, 1, False), (3, 2, False), (1, 1, False), (5, 4, False), (10, 10, False), (4, 3, True), (0, 2, True), (2, 5, False)]:
+# (the NB shapes run two workgroups per CU; (20, 10), (13, 11), (20, 20) take the sub-launch route)
+for (n, m, nb) in [(0, 3, False), (0, 1, False), (3, 2, False), (1, 1, False), (5, 4, False), (10, 10, False), (4, 3, True), (0, 2, True),
+                   (2, 5, False), (10, 10, True), (20, 9, True), (20, 10, False), (13, 11, False), (20, 20, False)]:
     rng = np.random.default_rng(1000 + 31 * n + m)
-    rows = 20_011
+    rows = 200_011 if n + m >= 20 else 20_011
     num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
     cat = [rng.integers(-2, 5, rows).astype(np.int32) for _ in range(m)]
     want = blob_to_dict(orc.State(orc.WIDE).update(num, cat, nb=nb).finalize())
