@@ -24,55 +24,102 @@ __device__ inline void pair_decode(int q, int m, int &c1, int &c2) {
 }
 
 // ---- to_cofactor ---------------------------------------------------------------------------------
-// One thread per written element; every array is written front to back, fully coalesced.
+// A workgroup lifts a tile of 256 rows: the tile's inputs go to LDS once (every x_j is used
+// 1 + n + m times), then each output array's segment of the tile — contiguous in memory — is
+// written front to back by all threads, element e of the segment by thread e mod 256 (coalesced,
+// 16-byte stores for the list entries).  All index arithmetic is 32-bit inside the tile (row = e /
+// W through a multiply-high with W's reciprocal); the first version, one thread per element of
+// the whole output with 64-bit divisions, was ALU-bound at 2.3-2.7 TB/s written.
+constexpr int LIFT_ROWS = 256;
+struct LiftDiv { unsigned mul; };                   // e / w == __umulhi(e, mul) for e * w < 2^32
+__host__ __device__ inline LiftDiv lift_div(unsigned w) { return LiftDiv{w <= 1 ? 0u : (unsigned)(0x100000000ull / w) + 1u}; }
+__device__ __forceinline__ unsigned lift_quot(unsigned e, unsigned w, LiftDiv d) { return w <= 1 ? e : __umulhi(e, d.mul); }
+
 __global__ __launch_bounds__(256) void lift_kernel(NumCols num, CatCols cat, int n, int m, int kind, uint64_t rows,
                                                    cofactor_tvec o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lift_lds[];
   const int T = kind ? n : tri_i(n), Tm = kind ? 0 : tri_i(m), nm = kind ? 0 : n * m;
-  // work items per row: 1 N + n lin + T quad + 5 outer/row entries + m lc (sub, key, val) + nm nc + Tm cc
-  const uint64_t per_row = 1 + (uint64_t)n + T + 5 + m + nm + Tm;
-  const uint64_t total = rows * per_row;
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (uint64_t)gridDim.x * blockDim.x) {
-    // arrays in turn, each of length rows * (its items per row)
-    uint64_t u = w;
-    if (u < rows) { o.N[u] = 1; continue; }
-    u -= rows;
-    if (u < rows * n) { const uint64_t i = u / n; const int k = (int)(u % n); o.lin[u] = num.p[k][i]; continue; }
-    u -= rows * n;
-    if (u < rows * T) {
-      const uint64_t i = u / T; int q = (int)(u % T), j = 0, k;
-      if (kind) { j = k = q; }
-      else { while (q >= n - j) { q -= n - j; j++; } k = j + q; }
-      o.quad[u] = num.p[j][i] * num.p[k][i];        // float product, as the reference stores it (lift.cpp:119-136)
-      continue;
+  float *xs = reinterpret_cast<float *>(lift_lds);                       // [n][LIFT_ROWS]
+  int32_t *ks = reinterpret_cast<int32_t *>(xs + n * LIFT_ROWS);         // [m][LIFT_ROWS]
+  unsigned char *qa = reinterpret_cast<unsigned char *>(ks + m * LIFT_ROWS);   // quad entry q -> (j, k)
+  unsigned char *qb = qa + 256;
+  unsigned char *pa = qb + 256;                                          // quad_cat sub-list s -> (c1, c2)
+  unsigned char *pb = pa + 256;
+  const int tid = threadIdx.x;
+  for (int q = tid; q < T; q += 256) {
+    int j = 0, r = q, k;
+    if (kind) { j = k = q; }
+    else { while (r >= n - j) { r -= n - j; j++; } k = j + r; }
+    qa[q] = (unsigned char)j; qb[q] = (unsigned char)k;
+  }
+  for (int s = tid; s < Tm; s += 256) {
+    int c1, c2;
+    pair_decode(s, m, c1, c2);
+    pa[s] = (unsigned char)c1; pb[s] = (unsigned char)c2;
+  }
+  const LiftDiv dn = lift_div(n), dT = lift_div(T), dm = lift_div(m), dnm = lift_div(nm), dTm = lift_div(Tm);
+  const uint64_t ntiles = (rows + LIFT_ROWS - 1) / LIFT_ROWS;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t row0 = tile * LIFT_ROWS;
+    const unsigned R = (unsigned)min<uint64_t>(LIFT_ROWS, rows - row0);
+    __syncthreads();                                 // (previous tile's readers done; tables written)
+    for (int k = 0; k < n; k++)
+      if ((unsigned)tid < R) xs[k * LIFT_ROWS + tid] = num.p[k][row0 + tid];
+    for (int c = 0; c < m; c++)
+      if ((unsigned)tid < R) ks[c * LIFT_ROWS + tid] = cat.p[c][row0 + tid];
+    __syncthreads();
+    if ((unsigned)tid < R) {                         // per-row items: N and the five outer list entries
+      const uint64_t i = row0 + tid;
+      o.N[i] = 1;
+      reinterpret_cast<u64x2 *>(o.lin_e)[i] = u64x2{i * n, (unsigned long long)n};
+      reinterpret_cast<u64x2 *>(o.quad_e)[i] = u64x2{i * T, (unsigned long long)T};
+      if (o.lc_outer) reinterpret_cast<u64x2 *>(o.lc_outer)[i] = u64x2{i * m, (unsigned long long)m};
+      if (!kind && o.nc_outer) reinterpret_cast<u64x2 *>(o.nc_outer)[i] = u64x2{i * nm, (unsigned long long)nm};
+      if (!kind && o.cc_outer) reinterpret_cast<u64x2 *>(o.cc_outer)[i] = u64x2{i * Tm, (unsigned long long)Tm};
     }
-    u -= rows * T;
-    if (u < rows) { o.lin_e[2 * u] = u * n; o.lin_e[2 * u + 1] = n; continue; }
-    u -= rows;
-    if (u < rows) { o.quad_e[2 * u] = u * T; o.quad_e[2 * u + 1] = T; continue; }
-    u -= rows;
-    if (u < rows) { if (o.lc_outer) { o.lc_outer[2 * u] = u * m; o.lc_outer[2 * u + 1] = m; } continue; }
-    u -= rows;
-    if (u < rows) { if (!kind && o.nc_outer) { o.nc_outer[2 * u] = u * nm; o.nc_outer[2 * u + 1] = nm; } continue; }
-    u -= rows;
-    if (u < rows) { if (!kind && o.cc_outer) { o.cc_outer[2 * u] = u * Tm; o.cc_outer[2 * u + 1] = Tm; } continue; }
-    u -= rows;
-    if (u < rows * m) {                              // lin_cat: [{key, 1}] per key column (lift.cpp:94-105)
-      const uint64_t i = u / m; const int c = (int)(u % m);
-      o.lc_sub[2 * u] = u; o.lc_sub[2 * u + 1] = 1; o.lc_key[u] = cat.p[c][i]; o.lc_val[u] = 1.f;
-      continue;
+    {                                                // lin: [R][n]
+      float *dst = o.lin + row0 * n;
+      for (unsigned e = tid; e < R * n; e += 256) {
+        const unsigned r = lift_quot(e, n, dn), k = e - r * n;
+        dst[e] = xs[k * LIFT_ROWS + r];
+      }
     }
-    u -= rows * m;
-    if (u < rows * nm) {                             // quad_num_cat[(j m + c)] = [{key_c, x_j}] (lift.cpp:156-176)
-      const uint64_t i = u / nm; const int s = (int)(u % nm), j = s / m, c = s % m;
-      o.nc_sub[2 * u] = u; o.nc_sub[2 * u + 1] = 1; o.nc_key[u] = cat.p[c][i]; o.nc_val[u] = num.p[j][i];
-      continue;
+    {                                                // quad: [R][T], float products as the reference stores them (lift.cpp:119-136)
+      float *dst = o.quad + row0 * T;
+      for (unsigned e = tid; e < R * T; e += 256) {
+        const unsigned r = lift_quot(e, T, dT), q = e - r * T;
+        dst[e] = xs[qa[q] * LIFT_ROWS + r] * xs[qb[q] * LIFT_ROWS + r];
+      }
     }
-    u -= rows * nm;
-    {                                               // quad_cat[(c1, c2 >= c1)] = [{k1, k2, 1}] (lift.cpp:199-219)
-      const uint64_t i = u / Tm; int c1, c2;
-      pair_decode((int)(u % Tm), m, c1, c2);
-      o.cc_sub[2 * u] = u; o.cc_sub[2 * u + 1] = 1;
-      o.cc_key1[u] = cat.p[c1][i]; o.cc_key2[u] = cat.p[c2][i]; o.cc_val[u] = 1.f;
+    if (m > 0) {                                     // lin_cat: [{key, 1}] per key column (lift.cpp:94-105)
+      const uint64_t u0 = row0 * m;
+      for (unsigned e = tid; e < R * m; e += 256) {
+        const unsigned r = lift_quot(e, m, dm), c = e - r * m;
+        reinterpret_cast<u64x2 *>(o.lc_sub)[u0 + e] = u64x2{u0 + e, 1ull};
+        o.lc_key[u0 + e] = ks[c * LIFT_ROWS + r];
+        o.lc_val[u0 + e] = 1.f;
+      }
+    }
+    if (!kind && nm > 0) {                           // quad_num_cat[(j m + c)] = [{key_c, x_j}] (lift.cpp:156-176)
+      const uint64_t u0 = row0 * nm;
+      for (unsigned e = tid; e < R * nm; e += 256) {
+        const unsigned r = lift_quot(e, nm, dnm), s = e - r * nm;
+        const unsigned j = lift_quot(s, m, dm), c = s - j * m;
+        reinterpret_cast<u64x2 *>(o.nc_sub)[u0 + e] = u64x2{u0 + e, 1ull};
+        o.nc_key[u0 + e] = ks[c * LIFT_ROWS + r];
+        o.nc_val[u0 + e] = xs[j * LIFT_ROWS + r];
+      }
+    }
+    if (!kind && Tm > 0) {                           // quad_cat[(c1, c2 >= c1)] = [{k1, k2, 1}] (lift.cpp:199-219)
+      const uint64_t u0 = row0 * Tm;
+      for (unsigned e = tid; e < R * Tm; e += 256) {
+        const unsigned r = lift_quot(e, Tm, dTm), s = e - r * Tm;
+        reinterpret_cast<u64x2 *>(o.cc_sub)[u0 + e] = u64x2{u0 + e, 1ull};
+        o.cc_key1[u0 + e] = ks[pa[s] * LIFT_ROWS + r];
+        o.cc_key2[u0 + e] = ks[pb[s] * LIFT_ROWS + r];
+        o.cc_val[u0 + e] = 1.f;
+      }
     }
   }
 }
@@ -616,9 +663,10 @@ int grid_for(uint64_t items) {
 hipError_t launch_lift(const NumCols &num, const CatCols &cat, int n, int m, int kind, uint64_t rows,
                        const cofactor_tvec &out, hipStream_t stream) {
   if (rows == 0) return hipSuccess;
-  const int T = kind ? n : tri_i(n), Tm = kind ? 0 : tri_i(m), nm = kind ? 0 : n * m;
-  const uint64_t total = rows * (1 + (uint64_t)n + T + 5 + m + nm + Tm);
-  hipLaunchKernelGGL(lift_kernel, dim3(grid_for(total)), dim3(256), 0, stream, num, cat, n, m, kind, rows, out);
+  const size_t lds = (size_t)(n + m) * LIFT_ROWS * 4 + 1024;
+  const uint64_t ntiles = (rows + LIFT_ROWS - 1) / LIFT_ROWS;
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, 8192);
+  hipLaunchKernelGGL(lift_kernel, dim3(grid), dim3(256), lds, stream, num, cat, n, m, kind, rows, out);
   return hipGetLastError();
 }
 
