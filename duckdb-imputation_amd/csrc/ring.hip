@@ -478,13 +478,19 @@ __global__ __launch_bounds__(GR_THREADS) void groups_accumulate_kernel(const int
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int rr = 0; rr < nvalid; rr++) {
+    // narrow triples: W = the cell count rounded up to a power of two lanes per row, 64 / W rows
+    // side by side (15 cells at 2_2 would leave 49 of the 64 lanes idle)
+    const int ncell = Dd + ncat;
+    int W = 64;
+    while (W / 2 >= ncell && W > 1) W >>= 1;
+    const int RP = 64 / W, lrow = lane / W, lcell = lane - lrow * W;
+    for (int rr = lrow; rr < nvalid; rr += RP) {
       const float *x = xs + rr * stride + 1;
       const int *cd = is + rr * stride + 1 + n;
       const int g = is[rr * stride];
-      if (g < 0) { if (lane == 0) D.flags[1] = 1; continue; }
+      if (g < 0) { if (lcell == 0) D.flags[1] = 1; continue; }
       double *row = tab + (long long)g * dtot;
-      for (int cell = lane; cell < Dd + ncat; cell += 64) {
+      for (int cell = lcell; cell < ncell; cell += W) {
         long long idx = cell;
         double val;
         if (cell == 0) val = 1.0;
