@@ -246,6 +246,8 @@ def multiply(ctx, a, b, a_sel=None, b_sel=None, rows=None):
     _check(fn(ctx._h, C.byref(a.struct), pa, C.byref(b.struct), pb, rows, None, C.byref(need[0]), C.byref(need[1]), C.byref(need[2])))
     out = TVec(rows, a.n + b.n, a.m + b.m, a.kind, need[0].value, need[1].value, need[2].value, device=dev)
     _check(fn(ctx._h, C.byref(a.struct), pa, C.byref(b.struct), pb, rows, C.byref(out.struct), None, None, None))
+    if dev is not None:
+        ctx.synchronize()          # the device form is asynchronous on the context stream
     return out
 
 

@@ -1168,6 +1168,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->pair_slabs);
   (void)hipFree(ctx->skip);
   (void)hipFree(ctx->ring_red);
+  (void)hipFree(ctx->ring_scratch);
   (void)hipFree(ctx->code_cache);
   (void)hipFree(ctx->pair_tmp);
   sparse_scratch_free(ctx->sparse_sc);

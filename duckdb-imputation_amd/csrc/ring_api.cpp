@@ -228,18 +228,45 @@ cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec 
   CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   hipStream_t st = ctx->stream;
-  DevBuf len[3], offs[3];
-  uint64_t need[3] = {0, 0, 0};
-  cofactor_tvec none{};
+  // sub-list lengths, their exclusive scans and the scans' temporaries: carved from one context
+  // scratch block (no allocation per call), all three families enqueued before the ONE
+  // synchronisation that brings the three payload sizes back
+  uint64_t items[3], need[3] = {0, 0, 0};
+  size_t temp_bytes[3] = {0, 0, 0}, total_bytes = 0;
   for (int f = 0; f < 3; f++) {
-    const uint64_t items = rows * per[f];
-    if (items == 0) continue;
-    HIP_TRY(len[f].alloc(items * 8));
-    HIP_TRY(offs[f].alloc(items * 8));
-    HIP_TRY(launch_mul_lists(*a, d_a_sel, *b, d_b_sel, rows, f, len[f].as<uint64_t>(), nullptr, none, 0, st));
-    cofactor_status s = scan_lengths(ctx, len[f].as<uint64_t>(), offs[f].as<uint64_t>(), items, &need[f]);
-    if (s != COFACTOR_OK) return s;
+    items[f] = rows * per[f];
+    if (items[f] > 0x7fffffffull) return fail(COFACTOR_ERR_UNSUPPORTED, "too many sub-lists for one call");
+    if (items[f] == 0) continue;
+    HIP_TRY(ring_exclusive_scan(nullptr, nullptr, items[f], nullptr, &temp_bytes[f], st));
+    total_bytes += items[f] * 16 + ((temp_bytes[f] + 255) & ~(size_t)255) + 512;
   }
+  if (total_bytes > ctx->ring_scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(st));               // kernels of earlier calls may still read the old block
+    (void)hipFree(ctx->ring_scratch);
+    ctx->ring_scratch = nullptr;
+    ctx->ring_scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->ring_scratch, total_bytes + total_bytes / 4));
+    ctx->ring_scratch_bytes = total_bytes + total_bytes / 4;
+  }
+  uint64_t *len[3] = {nullptr, nullptr, nullptr}, *offs[3] = {nullptr, nullptr, nullptr};
+  uint64_t tail[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  cofactor_tvec none{};
+  {
+    char *cur = reinterpret_cast<char *>(ctx->ring_scratch);
+    auto take = [&](size_t bytes) { char *at = cur; cur += (bytes + 255) & ~(size_t)255; return at; };
+    for (int f = 0; f < 3; f++) {
+      if (items[f] == 0) continue;
+      len[f] = reinterpret_cast<uint64_t *>(take(items[f] * 8));
+      offs[f] = reinterpret_cast<uint64_t *>(take(items[f] * 8));
+      void *temp = take(temp_bytes[f]);
+      HIP_TRY(launch_mul_lists(*a, d_a_sel, *b, d_b_sel, rows, f, len[f], nullptr, none, 0, st));
+      HIP_TRY(ring_exclusive_scan(len[f], offs[f], items[f], temp, &temp_bytes[f], st));
+      HIP_TRY(hipMemcpyAsync(&tail[f][0], offs[f] + items[f] - 1, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&tail[f][1], len[f] + items[f] - 1, 8, hipMemcpyDeviceToHost, st));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int f = 0; f < 3; f++) need[f] = tail[f][0] + tail[f][1];
   if (lc_need) *lc_need = need[0];
   if (nc_need) *nc_need = need[1];
   if (cc_need) *cc_need = need[2];
@@ -251,9 +278,9 @@ cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec 
   if (!tvec_dense_ok(out) || !tvec_lists_ok(out)) return fail(COFACTOR_ERR_INVALID, "multiply: an output array is null");
   HIP_TRY(launch_mul_dense(*a, d_a_sel, *b, d_b_sel, rows, *out, st));
   for (int f = 0; f < 3; f++)
-    if (rows * per[f])
-      HIP_TRY(launch_mul_lists(*a, d_a_sel, *b, d_b_sel, rows, f, nullptr, offs[f].as<uint64_t>(), *out, 1, st));
-  HIP_TRY(hipStreamSynchronize(st));                 // the offset arrays are freed on return
+    if (items[f])
+      HIP_TRY(launch_mul_lists(*a, d_a_sel, *b, d_b_sel, rows, f, nullptr, offs[f], *out, 1, st));
+  // (asynchronous from here, like every device entry point: the scratch block stays the context's)
   return COFACTOR_OK;
 }
 

@@ -49,6 +49,8 @@ struct cofactor_ctx {
   size_t skip_bytes = 0;
   size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
   double *ring_red = nullptr;   // 256 doubles: reduced dense children of a vector of triples (sum_triple)
+  void *ring_scratch = nullptr; // multiply_triple: sub-list lengths / offsets / scan temporaries (grown on demand)
+  size_t ring_scratch_bytes = 0;
   // multi-pass generic path: 16-bit key codes of the batch ([column][stride]) and the u32 cells of a
   // pair table too big for LDS
   unsigned short *code_cache = nullptr;

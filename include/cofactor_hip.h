@@ -303,7 +303,9 @@ cofactor_status cofactor_agg_update_tvec_device(cofactor_agg *agg, const cofacto
  * (b_sel ? b_sel[i] : i), i < rows (the selection vectors are what a join hands the function).
  * Two-call protocol on the payload sizes: with out == NULL (or capacities too small ->
  * COFACTOR_ERR_CAPACITY) only *lc_need / *nc_need / *cc_need are set (entries of the three payload
- * arrays).  N is the int32 product, as in the reference (mul.cpp:46-49). */
+ * arrays).  N is the int32 product, as in the reference (mul.cpp:46-49).  The size query
+ * synchronises (it returns numbers); the fill is asynchronous on the context stream like the other
+ * device entry points (cofactor_ctx_synchronize before another stream reads `out`). */
 cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec *a,
                                          const uint32_t *d_a_sel, const cofactor_tvec *b,
                                          const uint32_t *d_b_sel, uint64_t rows, cofactor_tvec *out,

@@ -64,6 +64,14 @@ def main():
                 prod = ring.multiply(ctx, A, A, sel, sel)
             torch.cuda.synchronize()
             out["multiply_2_2x2_2"] = {"pairs": G, "pairs_per_s": G / ((time.perf_counter() - t0) / 3)}
+            big = np.tile(sel, 20)                  # 2e6 pairs in one call: the kernels' own rate
+            prod = ring.multiply(ctx, A, A, big, big)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                prod = ring.multiply(ctx, A, A, big, big)
+            torch.cuda.synchronize()
+            out["multiply_2_2x2_2_big"] = {"pairs": len(big), "pairs_per_s": len(big) / ((time.perf_counter() - t0) / 3)}
+            del prod
         grp.close()
     print(json.dumps(out))
     ctx.close()
