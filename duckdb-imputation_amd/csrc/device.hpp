@@ -168,6 +168,10 @@ __device__ __forceinline__ void cat_dict_insert(unsigned long long *slots, int c
       if (old == 0ull || old == want) return;
     }
     h = (h + 1) & (cap - 1);
+    // a table that somebody already found full is grown and the batch re-run: stop probing it (a
+    // full table of `cap` slots costs `cap` dependent loads per key; 2e7 keys against a table
+    // sized for 1e3 took seconds)
+    if ((probe & 31) == 31 && __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   }
   flags[0] = 1;
 }
