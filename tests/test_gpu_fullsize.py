@@ -182,7 +182,7 @@ def test_narrow_tables_exact_through_the_tile_ring(ctx, n):
                 q += 1
 
 
-@pytest.mark.parametrize("n", [4, 10, 20])
+@pytest.mark.parametrize("n", [4, 10, 14, 16, 20])
 def test_unaligned_columns_exact_through_the_tile_ring(ctx, n):
     """Same as above for columns that are only 4-byte aligned (dword loads instead of dwordx4)."""
     import torch

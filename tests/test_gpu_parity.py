@@ -302,7 +302,7 @@ def test_random_shapes_exact(ctx):
         assert got == want, (trial, n, m, nb, keys, rows)
 
 
-@pytest.mark.parametrize("n,m,keys", [(20, 0, 0), (3, 2, 6), (10, 10, 16), (0, 3, 40), (5, 4, 300)])
+@pytest.mark.parametrize("n,m,keys", [(20, 0, 0), (3, 2, 6), (10, 10, 16), (0, 3, 40), (5, 4, 300), (13, 0, 0), (16, 0, 0), (15, 2, 5)])
 def test_masked_update_equals_filtered_rows(ctx, n, m, keys):
     """cofactor_agg_update_device_masked == the aggregate over the kept rows only (the WHERE
     <col>_IS_NULL IS FALSE filter of the MICE drivers), N included; mixed with an unmasked update."""
@@ -731,3 +731,25 @@ def test_wide_shapes_take_their_per_key_sums_through_sub_launches(monkeypatch, n
         assert blob_to_dict(blob) == blob_to_dict(ref.finalize())
         blobs.append(blob)
     assert np.array_equal(blobs[0], blobs[1])
+
+
+def test_staging_blocks_are_reused_by_the_next_state(ctx):
+    """The DataChunk path's pinned staging blocks go to a pool in the context when a state dies or
+    outgrows them; the next state of the same shape takes them over.  Three generations of states
+    over the same host table (enough rows to grow the block twice) must all give the oracle's triple."""
+    rng = np.random.default_rng(77)
+    rows = 150_000
+    num, cat = int_table(rng, rows, 4, 2)
+    want = blob_to_dict(orc.State(orc.FAITHFUL).update(num, cat).finalize())
+    for gen in range(3):
+        aggs = [ctx.aggregate(4, 2) for _ in range(3)]
+        for i, a in enumerate(aggs):
+            lo, hi = rows * i // 3, rows * (i + 1) // 3
+            for c0 in range(lo, hi, 2048):                       # DuckDB-sized chunks
+                c1 = min(hi, c0 + 2048)
+                a.update_host([c[c0:c1] for c in num], [c[c0:c1] for c in cat])
+        aggs[0].combine(aggs[1]); aggs[0].combine(aggs[2])
+        got = blob_to_dict(aggs[0].finalize())
+        for a in aggs:
+            a.close()
+        assert got == want, gen
