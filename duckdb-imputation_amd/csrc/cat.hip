@@ -525,9 +525,18 @@ hipError_t launch_cat_tables_import(const CatLayout &L, const CatDevice &D, cons
 //                      stays in L2 / MALL (1 M cells = 4 MB) instead of 55 tables thrashing HBM
 constexpr unsigned short CODE_NONE = 0xFFFFu;
 
+template <bool LDS_DICT>
 __global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t rows, uint64_t stride, CatLayout L, CatDevice D,
                                                         const uint8_t *__restrict__ mask, unsigned short *__restrict__ codes) {
-  // four rows per thread, one column at a time: 16-B key loads, 8-B code stores
+  // four rows per thread, one column at a time: 16-B key loads, 8-B code stores; the dictionaries
+  // are probed in an LDS copy when they fit (LDS_DICT), else in HBM / L2
+  extern __shared__ __attribute__((aligned(16))) unsigned char codes_lds[];
+  unsigned long long *l_slot = reinterpret_cast<unsigned long long *>(codes_lds);
+  int32_t *l_code = reinterpret_cast<int32_t *>(l_slot + (LDS_DICT ? L.n_slots : 0));
+  if (LDS_DICT) {
+    for (int i = threadIdx.x; i < L.n_slots; i += 256) { l_slot[i] = D.ht_slot[i]; l_code[i] = D.ht_code[i]; }
+    __syncthreads();
+  }
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const uint64_t nq = (rows + 3) / 4;
   for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * blockDim.x) {
@@ -545,7 +554,8 @@ __global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t ro
       for (int e = 0; e < 4; e++) {
         out[e] = CODE_NONE;
         if (e < cnt && ((keep >> e) & 1)) {
-          const int code = cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], kv[e]);
+          const int code = LDS_DICT ? cat_lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], kv[e])
+                                    : cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], kv[e]);
           if (code < 0 || code >= L.kc[c]) D.flags[1] = 1;
           else if (code < 0xFFFF) out[e] = (unsigned short)code;   // (beyond: a wide column, never read from the cache)
         }
@@ -667,7 +677,11 @@ hipError_t launch_cat_codes(const CatCols &cat, uint64_t rows, uint64_t stride, 
   if (rows == 0 || L.m == 0) return hipSuccess;
   const uint64_t nq = (rows + 3) / 4;
   const int grid = (int)std::min<uint64_t>((nq + 255) / 256, 8192);
-  hipLaunchKernelGGL(cat_codes_kernel, dim3(grid), dim3(256), 0, stream, cat, rows, stride, L, D, mask, codes);
+  const size_t dict = (size_t)L.n_slots * 12;
+  if (dict <= 48 * 1024)
+    hipLaunchKernelGGL((cat_codes_kernel<true>), dim3(grid), dim3(256), dict, stream, cat, rows, stride, L, D, mask, codes);
+  else
+    hipLaunchKernelGGL((cat_codes_kernel<false>), dim3(grid), dim3(256), 0, stream, cat, rows, stride, L, D, mask, codes);
   return hipGetLastError();
 }
 
