@@ -666,6 +666,48 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_pairs_kernel(const unsigned s
   }
 }
 
+// The same for the launches with LDS tables (several pairs per launch), with the 4 rows' codes of ALL
+// key columns in registers: the generic kernel above re-loads column c2's codes for every pair
+// (c1, c2) — at 20 columns that is ~105 loads of 8 bytes per 4 rows and launch, 10 GB per
+// 5e7-row launch out of L2 / HBM, more than the table scan itself.  MC = m rounded up to a
+// multiple of 4 (compile-time: register arrays need static indices); the pair loops are fully
+// unrolled, a pair outside this launch's mask costs one scalar bit test.
+template <int MC>
+__global__ __launch_bounds__(CAT_THREADS) void cat_pairs_reg_kernel(const unsigned short *__restrict__ codes, uint64_t rows,
+                                                                    uint64_t stride, CatLayout L, CatDevice D, CatPass P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned *l_p = reinterpret_cast<unsigned *>(lds_raw);
+  const int m = L.m, tid = threadIdx.x;
+  for (int i = tid; i < P.p_cells; i += CAT_THREADS) l_p[i] = 0u;
+  __syncthreads();
+  const uint64_t nq = (rows + 3) / 4, step = (uint64_t)gridDim.x * CAT_THREADS;
+  for (uint64_t qd = (uint64_t)blockIdx.x * CAT_THREADS + tid; qd < nq; qd += step) {
+    const uint64_t r = 4 * qd;
+    uint2 cd[MC];
+#pragma unroll
+    for (int c = 0; c < MC; c++)
+      cd[c] = c < m ? *reinterpret_cast<const uint2 *>(codes + (uint64_t)c * stride + r) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+    for (int c1 = 0; c1 < MC; c1++) {
+#pragma unroll
+      for (int c2 = c1; c2 < MC; c2++) {
+        if (c2 >= m) continue;
+        const int q = c1 * m - c1 * (c1 - 1) / 2 + (c2 - c1);
+        if (!((P.pair_mask[q >> 5] >> (q & 31)) & 1u)) continue;
+        const int off = L.p_off[q] - P.p_base, kc2 = L.kc[c2];
+        const unsigned ca[4] = {cd[c1].x & 0xFFFFu, cd[c1].x >> 16, cd[c1].y & 0xFFFFu, cd[c1].y >> 16};
+        const unsigned cb[4] = {cd[c2].x & 0xFFFFu, cd[c2].x >> 16, cd[c2].y & 0xFFFFu, cd[c2].y >> 16};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (ca[e] != CODE_NONE && cb[e] != CODE_NONE) atomicAdd(&l_p[off + ca[e] * kc2 + cb[e]], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < P.p_cells; i += CAT_THREADS)
+    if (l_p[i]) atomicAdd(&D.p[P.p_base + i], (unsigned long long)l_p[i]);
+}
+
 __global__ __launch_bounds__(256) void cat_fold_u32_kernel(const unsigned *__restrict__ src, long long cells,
                                                            unsigned long long *__restrict__ dst) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x)
@@ -716,11 +758,17 @@ hipError_t launch_cat_pairs(const unsigned short *codes, uint64_t rows, uint64_t
     hipLaunchKernelGGL((cat_pairs_kernel<false>), dim3(grid), dim3(CAT_THREADS), 0, stream, codes, rows, stride, L, D, P, gtab);
   } else {
     const size_t lds = (size_t)P.p_cells * 4;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void *)cat_pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
+    hipError_t e = hipErrorInvalidValue;
+    switch ((L.m + 3) / 4) {
+#define CASE(Q) case Q: \
+        e = lds > 48 * 1024 ? hipFuncSetAttribute((const void *)cat_pairs_reg_kernel<4 * Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess; \
+        if (e == hipSuccess) hipLaunchKernelGGL((cat_pairs_reg_kernel<4 * Q>), dim3(grid), dim3(CAT_THREADS), lds, stream, codes, rows, stride, L, D, P); \
+        break;
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5)
+#undef CASE
+      default: break;
     }
-    hipLaunchKernelGGL((cat_pairs_kernel<true>), dim3(grid), dim3(CAT_THREADS), lds, stream, codes, rows, stride, L, D, P, gtab);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }
