@@ -520,9 +520,10 @@ hipError_t launch_cat_tables_import(const CatLayout &L, const CatDevice &D, cons
 // per key instead of 4, no dictionary probes, four rows per thread.
 //   cat_codes_kernel   keys -> codes
 //   cat_sums_kernel    key counts + per-key sums of a subset of the key columns (LDS tables)
-//   cat_pairs_kernel   pair tables of a run of column pairs (LDS tables), or ONE pair table too big
-//                      for LDS as u32 cells in HBM: it is the only table written in that launch, so it
-//                      stays in L2 / MALL (1 M cells = 4 MB) instead of 55 tables thrashing HBM
+//   cat_pairs_reg_kernel  pair tables of a run of column pairs (LDS tables)
+//   cat_pair_hbm_kernel   ONE pair table too big for LDS as u32 cells in HBM: it is the only table
+//                         written in that launch, so it stays in L2 / MALL (1 M cells = 4 MB)
+//                         instead of 55 tables thrashing HBM
 constexpr unsigned short CODE_NONE = 0xFFFFu;
 
 template <bool LDS_DICT>
@@ -618,57 +619,37 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_sums_kernel(NumCols num, cons
   }
 }
 
-// pair tables of the pairs in P.pair_mask.  LDS_TABLES: u32 cells in LDS covering D.p cells
-// [P.p_base, P.p_base + P.p_cells), added to D.p at the end.  Otherwise exactly one pair, u32
-// cells in `gtab` (zeroed by the caller, folded into D.p by cat_fold_u32_kernel).
-template <bool LDS_TABLES>
-__global__ __launch_bounds__(CAT_THREADS) void cat_pairs_kernel(const unsigned short *__restrict__ codes, uint64_t rows,
-                                                                uint64_t stride, CatLayout L, CatDevice D, CatPass P,
-                                                                unsigned *__restrict__ gtab) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  unsigned *l_p = reinterpret_cast<unsigned *>(lds_raw);
+// ONE pair table too big for LDS: u32 cells in `gtab` (zeroed by the caller, folded into D.p by
+// cat_fold_u32_kernel); P.pair_mask names the pair.
+__global__ __launch_bounds__(CAT_THREADS) void cat_pair_hbm_kernel(const unsigned short *__restrict__ codes, uint64_t rows,
+                                                                   uint64_t stride, CatLayout L, CatPass P,
+                                                                   unsigned *__restrict__ gtab) {
   const int m = L.m, tid = threadIdx.x;
-  if (LDS_TABLES) {
-    for (int i = tid; i < P.p_cells; i += CAT_THREADS) l_p[i] = 0u;
-    __syncthreads();
+  int c1 = 0, c2 = 0;
+  {
+    int q = 0;
+    for (int a = 0; a < m; a++)
+      for (int b = a; b < m; b++, q++)
+        if ((P.pair_mask[q >> 5] >> (q & 31)) & 1u) { c1 = a; c2 = b; }
   }
-  const int npairs = m * (m + 1) / 2;
+  const int kc2 = L.kc[c2];
   const uint64_t nq = (rows + 3) / 4, step = (uint64_t)gridDim.x * CAT_THREADS;
   for (uint64_t qd = (uint64_t)blockIdx.x * CAT_THREADS + tid; qd < nq; qd += step) {
     const uint64_t r = 4 * qd;
-    int q = 0;
-    for (int c1 = 0; c1 < m; c1++) {
-      uint2 a = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-      bool a_loaded = false;
-      for (int c2 = c1; c2 < m; c2++, q++) {
-        if (!((P.pair_mask[q >> 5] >> (q & 31)) & 1u)) continue;
-        if (!a_loaded) { a = *reinterpret_cast<const uint2 *>(codes + (uint64_t)c1 * stride + r); a_loaded = true; }
-        const uint2 b = c2 == c1 ? a : *reinterpret_cast<const uint2 *>(codes + (uint64_t)c2 * stride + r);
-        const int off = LDS_TABLES ? L.p_off[q] - P.p_base : 0;
-        const int kc2 = L.kc[c2];
-        const unsigned ca[4] = {a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, a.y >> 16};
-        const unsigned cb[4] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16};
+    const uint2 a = *reinterpret_cast<const uint2 *>(codes + (uint64_t)c1 * stride + r);
+    const uint2 b = c2 == c1 ? a : *reinterpret_cast<const uint2 *>(codes + (uint64_t)c2 * stride + r);
+    const unsigned ca[4] = {a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, a.y >> 16};
+    const unsigned cb[4] = {b.x & 0xFFFFu, b.x >> 16, b.y & 0xFFFFu, b.y >> 16};
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-          if (ca[e] != CODE_NONE && cb[e] != CODE_NONE) {       // (rows past the end hold CODE_NONE)
-            const unsigned idx = off + ca[e] * kc2 + cb[e];
-            if (LDS_TABLES) atomicAdd(&l_p[idx], 1u);
-            else atomicAdd(&gtab[idx], 1u);
-          }
-      }
-    }
-    (void)npairs;
-  }
-  if (LDS_TABLES) {
-    __syncthreads();
-    for (int i = tid; i < P.p_cells; i += CAT_THREADS)
-      if (l_p[i]) atomicAdd(&D.p[P.p_base + i], (unsigned long long)l_p[i]);
+    for (int e = 0; e < 4; e++)
+      if (ca[e] != CODE_NONE && cb[e] != CODE_NONE) atomicAdd(&gtab[ca[e] * kc2 + cb[e]], 1u);   // (rows past the end hold CODE_NONE)
   }
 }
 
-// The same for the launches with LDS tables (several pairs per launch), with the 4 rows' codes of ALL
-// key columns in registers: the generic kernel above re-loads column c2's codes for every pair
-// (c1, c2) — at 20 columns that is ~105 loads of 8 bytes per 4 rows and launch, 10 GB per
+// Pair tables that fit LDS together (several pairs per launch: P.pair_mask; u32 cells in LDS
+// covering D.p cells [P.p_base, P.p_base + P.p_cells), added to D.p at the end), with the 4 rows'
+// codes of ALL key columns in registers: re-loading column c2's codes for every pair (c1, c2), as
+// the first version did, is ~105 loads of 8 bytes per 4 rows and launch at 20 columns — 10 GB per
 // 5e7-row launch out of L2 / HBM, more than the table scan itself.  MC = m rounded up to a
 // multiple of 4 (compile-time: register arrays need static indices); the pair loops are fully
 // unrolled, a pair outside this launch's mask costs one scalar bit test.
@@ -755,7 +736,7 @@ hipError_t launch_cat_pairs(const unsigned short *codes, uint64_t rows, uint64_t
   const uint64_t need = ((rows + 3) / 4 + CAT_THREADS - 1) / CAT_THREADS;
   if ((uint64_t)grid > need) grid = (int)need;
   if (gtab) {
-    hipLaunchKernelGGL((cat_pairs_kernel<false>), dim3(grid), dim3(CAT_THREADS), 0, stream, codes, rows, stride, L, D, P, gtab);
+    hipLaunchKernelGGL(cat_pair_hbm_kernel, dim3(grid), dim3(CAT_THREADS), 0, stream, codes, rows, stride, L, P, gtab);
   } else {
     const size_t lds = (size_t)P.p_cells * 4;
     hipError_t e = hipErrorInvalidValue;
