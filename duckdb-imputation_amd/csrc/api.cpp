@@ -334,8 +334,14 @@ cofactor_status ensure_pair_slabs(cofactor_ctx *ctx, size_t bytes) {
 //        keys -> 16-bit codes once, then count / sum passes over column subsets and pair passes
 //        over runs of pair tables (LDS), one launch per pair table too big for LDS (u32 cells in
 //        HBM); columns past the 16-bit code cache and sparse pair tables as described there.
+// missed (optional): OPTIMISTIC call — the batch has not been through a dictionary pass.  The code
+// translation then runs first and reports a key missing from its dictionary through *missed with
+// NOTHING accumulated; the caller runs the dictionary pass and calls again without `missed`.
+// Routes whose kernels read raw keys (the single-launch kernel, batches of several pieces) set
+// *missed right away.
 cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCols &cat, uint64_t rows,
-                               bool timed = true, const uint8_t *mask = nullptr) {
+                               bool timed = true, const uint8_t *mask = nullptr, bool *missed = nullptr) {
+  if (missed) *missed = false;
   cofactor_ctx *ctx = a->ctx;
   hipStream_t st = ctx->stream;
   const CatLayout &L = a->L;
@@ -381,6 +387,10 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
   const bool mfma_pairs = small_keys && (mfma_sums || !do_s) && L.m <= 10 &&
                           fused2_applicable(Lp, a->nkeys_host, mask != nullptr, ctx->lds_max);
   const uint64_t piece = 1ull << 27;               // rows per code-cache fill / per sort
+  if (missed && (rows > piece || with_sparse || (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs))) {
+    *missed = true;                                  // (not a route the optimistic translation covers)
+    return COFACTOR_OK;
+  }
   if (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs) {   // one launch does all dense tables
     if (launch_cat_accumulate(num, cat, rows, L, a->D, passes[0], true, ctx->cat_grid, st, e0, e1, mask) != hipSuccess)
       return hip_fail(hipGetLastError(), "cat_accumulate");
@@ -412,6 +422,25 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
     // launch has already counted the keys of the body)
     const uint64_t s_from = (mfma_sums || (mfma_pairs && !do_s)) ? body : 0;
     const uint64_t p_from = mfma_pairs ? body : 0;
+    // ---- keys -> 16-bit codes for the rows the code-cache kernels handle ----
+    const uint64_t c_from = std::min(s_from, p_from);
+    cofactor_status s = COFACTOR_OK;
+    if (missed && c_from != 0) { *missed = true; return COFACTOR_OK; }     // (the one-hot kernels would meet raw keys)
+    if (c_from < prows) {
+      s = scratch_reserve(ctx, ctx->code_cache, ctx->code_cache_bytes, (size_t)L.m * stride * 2);
+      if (s != COFACTOR_OK) return s;
+      CatCols cc = pc;
+      for (int c = 0; c < L.m; c++) cc.p[c] = pc.p[c] + c_from;
+      if (missed) HIP_TRY(hipMemsetAsync(a->D.flags + 3, 0, sizeof(int32_t), st));
+      HIP_TRY(launch_cat_codes(cc, prows - c_from, stride, L, a->D, pmask ? pmask + c_from : nullptr,
+                               ctx->code_cache + c_from, st, missed != nullptr));
+      if (missed) {
+        int32_t miss = 0;
+        HIP_TRY(hipMemcpyAsync(&miss, a->D.flags + 3, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (miss) { *missed = true; return COFACTOR_OK; }
+      }
+    }
     if (body) {
       const int grid = fused2_grid(ctx->cus, ctx->gram_grid, body);
       const int sub_grid = !mfma_sums ? grid
@@ -438,17 +467,7 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
           c0 += mg;
         }
     }
-    // ---- the rest on 16-bit codes ----
-    const uint64_t c_from = std::min(s_from, p_from);
-    cofactor_status s = COFACTOR_OK;
-    if (c_from < prows) {
-      s = scratch_reserve(ctx, ctx->code_cache, ctx->code_cache_bytes, (size_t)L.m * stride * 2);
-      if (s != COFACTOR_OK) return s;
-      CatCols cc = pc;
-      for (int c = 0; c < L.m; c++) cc.p[c] = pc.p[c] + c_from;
-      HIP_TRY(launch_cat_codes(cc, prows - c_from, stride, L, a->D, pmask ? pmask + c_from : nullptr,
-                               ctx->code_cache + c_from, st));
-    }
+    // ---- the rest on the codes ----
     if (s_from < prows) {
       NumCols tn = pn;
       CatCols tc = pc;
@@ -595,10 +614,18 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
     optimistic = optimistic && fused_fits();
   }
   bool fused = optimistic;
+  // The same idea for the code-cache route: when every column has a dictionary and no one-pass kernel
+  // takes the shape, the dictionary pass is skipped and the code translation (which reads every key
+  // anyway) reports a miss before anything is accumulated.
+  bool generic_opt = false;
   if (a->m > 0 && !optimistic) {
-    cofactor_status s = cat_dictionaries(a, cat, rows);
-    if (s != COFACTOR_OK) return s;
-    fused = ctx->allow_fused && aligned && fused_fits();
+    generic_opt = allow_optimistic && ctx->allow_optimistic && a->cat_ready && !(ctx->allow_fused && aligned && fused_fits());
+    for (int c = 0; c < a->m && generic_opt; c++) generic_opt = a->nkeys_host[c] >= 1;
+    if (!generic_opt) {
+      cofactor_status s = cat_dictionaries(a, cat, rows);
+      if (s != COFACTOR_OK) return s;
+      fused = ctx->allow_fused && aligned && fused_fits();
+    }
   }
 #ifdef COFACTOR_DEV_ABLATE
   if (a->m > 0) {
@@ -694,8 +721,16 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
                           mask ? mask + done : nullptr));
     }
     if (a->m > 0) {
-      cofactor_status s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/!fused, mask ? mask + done : nullptr);
+      bool missed = false;
+      cofactor_status s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/!fused, mask ? mask + done : nullptr,
+                                         generic_opt ? &missed : nullptr);
       if (s != COFACTOR_OK) return s;
+      if (missed) {                                 // a new key (or a route without the check): dictionary pass, then again
+        s = cat_dictionaries(a, tcat, trows);
+        if (s != COFACTOR_OK) return s;
+        s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/false, mask ? mask + done : nullptr);
+        if (s != COFACTOR_OK) return s;
+      }
     }
   }
   if (a->m > 0) a->cat_check_pending = true;      // flags[1] is looked at by the next snapshot

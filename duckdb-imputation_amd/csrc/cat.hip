@@ -526,9 +526,13 @@ hipError_t launch_cat_tables_import(const CatLayout &L, const CatDevice &D, cons
 //                         instead of 55 tables thrashing HBM
 constexpr unsigned short CODE_NONE = 0xFFFFu;
 
+// miss_slot: which flag a key missing from its dictionary raises — 1 (sticky error: the dictionary
+// pass has run, this cannot happen) or 3 (optimistic run without a dictionary pass: the host then
+// runs the pass and redoes the batch; nothing has been accumulated yet).
 template <bool LDS_DICT>
 __global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t rows, uint64_t stride, CatLayout L, CatDevice D,
-                                                        const uint8_t *__restrict__ mask, unsigned short *__restrict__ codes) {
+                                                        const uint8_t *__restrict__ mask, unsigned short *__restrict__ codes,
+                                                        int miss_slot) {
   // four rows per thread, one column at a time: 16-B key loads, 8-B code stores; the dictionaries
   // are probed in an LDS copy when they fit (LDS_DICT), else in HBM / L2
   extern __shared__ __attribute__((aligned(16))) unsigned char codes_lds[];
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t ro
         if (e < cnt && ((keep >> e) & 1)) {
           const int code = LDS_DICT ? cat_lookup_code(l_slot + L.ht_off[c], l_code + L.ht_off[c], L.ht_cap[c], kv[e])
                                     : cat_lookup_code(D.ht_slot + L.ht_off[c], D.ht_code + L.ht_off[c], L.ht_cap[c], kv[e]);
-          if (code < 0 || code >= L.kc[c]) D.flags[1] = 1;
+          if (code < 0 || code >= L.kc[c]) D.flags[miss_slot] = 1;
           else if (code < 0xFFFF) out[e] = (unsigned short)code;   // (beyond: a wide column, never read from the cache)
         }
       }
@@ -696,15 +700,16 @@ __global__ __launch_bounds__(256) void cat_fold_u32_kernel(const unsigned *__res
 }
 
 hipError_t launch_cat_codes(const CatCols &cat, uint64_t rows, uint64_t stride, const CatLayout &L, const CatDevice &D,
-                            const uint8_t *mask, unsigned short *codes, hipStream_t stream) {
+                            const uint8_t *mask, unsigned short *codes, hipStream_t stream, bool optimistic) {
+  const int miss_slot = optimistic ? 3 : 1;
   if (rows == 0 || L.m == 0) return hipSuccess;
   const uint64_t nq = (rows + 3) / 4;
   const int grid = (int)std::min<uint64_t>((nq + 255) / 256, 8192);
   const size_t dict = (size_t)L.n_slots * 12;
   if (dict <= 48 * 1024)
-    hipLaunchKernelGGL((cat_codes_kernel<true>), dim3(grid), dim3(256), dict, stream, cat, rows, stride, L, D, mask, codes);
+    hipLaunchKernelGGL((cat_codes_kernel<true>), dim3(grid), dim3(256), dict, stream, cat, rows, stride, L, D, mask, codes, miss_slot);
   else
-    hipLaunchKernelGGL((cat_codes_kernel<false>), dim3(grid), dim3(256), 0, stream, cat, rows, stride, L, D, mask, codes);
+    hipLaunchKernelGGL((cat_codes_kernel<false>), dim3(grid), dim3(256), 0, stream, cat, rows, stride, L, D, mask, codes, miss_slot);
   return hipGetLastError();
 }
 

@@ -128,7 +128,7 @@ hipError_t launch_cat_relayout(const CatLayout &Lold, const CatDevice &Dold, con
 // Multi-pass generic path: keys -> 16-bit codes once ([column][stride], stride = rows rounded up to 4),
 // then count / sum passes over column subsets and pair passes that read the codes (cat.hip).
 hipError_t launch_cat_codes(const CatCols &cat, uint64_t rows, uint64_t stride, const CatLayout &L, const CatDevice &D,
-                            const uint8_t *mask, unsigned short *codes, hipStream_t stream);
+                            const uint8_t *mask, unsigned short *codes, hipStream_t stream, bool optimistic = false);
 size_t cat_sums_lds_bytes(const CatLayout &L, unsigned col_mask, bool do_s);
 hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
                            const CatLayout &L, const CatDevice &D, unsigned col_mask, int grid, hipStream_t stream);

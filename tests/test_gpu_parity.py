@@ -753,3 +753,35 @@ def test_staging_blocks_are_reused_by_the_next_state(ctx):
         for a in aggs:
             a.close()
         assert got == want, gen
+
+
+@pytest.mark.parametrize("n,m,k1,k2", [(2, 12, 6, 9), (3, 4, 40, 70), (2, 12, 10, 30), (0, 11, 5, 7)])
+def test_code_cache_route_without_a_dictionary_pass_meets_new_keys(ctx, n, m, k1, k2):
+    """Shapes no one-pass kernel takes: from the second batch on the dictionary pass is skipped and the
+    code translation reports keys it does not know before anything is accumulated.  Batch 2 repeats
+    batch 1's keys (no pass), batch 3 brings new keys (miss -> pass -> redo), batch 4 is filtered and
+    brings one more; reset keeps the dictionaries.  All against the oracle, exactly."""
+    import torch
+    rng = np.random.default_rng(9000 + 10 * n + m + k1)
+    agg = ctx.aggregate(n, m)
+    ref = orc.State(orc.FAITHFUL)
+    for step, (rows, k) in enumerate(((30_011, k1), (41_000, k1), (25_003, k2), (33_333, k2 + 1))):
+        num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+        cat = [(rng.integers(0, k, rows) * 3 - 7).astype(np.int32) for _ in range(m)]
+        dn = [torch.from_numpy(x).cuda() for x in num]
+        dc = [torch.from_numpy(x).cuda() for x in cat]
+        torch.cuda.synchronize()
+        if step == 3:
+            keep = (rng.random(rows) < 0.5).astype(np.uint8)
+            keep[:8] = 1
+            agg.update_device_masked(dn, dc, torch.from_numpy(keep).cuda())
+            sel = keep.astype(bool)
+            ref.update([x[sel] for x in num], [x[sel] for x in cat])
+        else:
+            agg.update_device(dn, dc)
+            ref.update(num, cat)
+        assert blob_to_dict(agg.finalize()) == blob_to_dict(ref.finalize()), step
+    agg.reset()
+    agg.update_device(dn, dc)
+    assert blob_to_dict(agg.finalize()) == blob_to_dict(orc.State(orc.FAITHFUL).update(num, cat).finalize())
+    agg.close()
