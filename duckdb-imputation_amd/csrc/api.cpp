@@ -350,11 +350,14 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
   bool hbm_needed = false;
   plan_cat_passes(L, ctx->lds_budget, passes, hbm, hbm_needed);
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->profiling && timed) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    ctx->cat_ev.emplace_back(e0, e1);
-  }
+  auto make_events = [&]() -> cofactor_status {     // (only on a path that records both)
+    if (ctx->profiling && timed) {
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      ctx->cat_ev.emplace_back(e0, e1);
+    }
+    return COFACTOR_OK;
+  };
   // pair tables kept as sorted lists: sort + merge per piece of the batch (sparse.hip)
   const bool with_sparse = L.kind == 0 && any_sparse_pair(L);
   auto sparse_step = [&](const CatCols &pc, const uint8_t *pmask, uint64_t prows) -> cofactor_status {
@@ -392,6 +395,10 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
     return COFACTOR_OK;
   }
   if (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs) {   // one launch does all dense tables
+    {
+      cofactor_status es = make_events();
+      if (es != COFACTOR_OK) return es;
+    }
     if (launch_cat_accumulate(num, cat, rows, L, a->D, passes[0], true, ctx->cat_grid, st, e0, e1, mask) != hipSuccess)
       return hip_fail(hipGetLastError(), "cat_accumulate");
     for (uint64_t off = 0; with_sparse && off < rows; off += piece) {
@@ -401,6 +408,20 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
       if (s != COFACTOR_OK) return s;
     }
     return COFACTOR_OK;
+  }
+  if (missed) {
+    // (the optimistic checks below can still give up before anything is timed: the event pair is
+    // made by the non-optimistic call that follows a miss, or here once the batch is known to go on)
+    bool al = (reinterpret_cast<uintptr_t>(mask) & 3) == 0;
+    for (int k = 0; k < L.n; k++) al = al && (reinterpret_cast<uintptr_t>(num.p[k]) & 15) == 0;
+    for (int c = 0; c < L.m; c++) al = al && (reinterpret_cast<uintptr_t>(cat.p[c]) & 15) == 0;
+    const uint64_t body0 = ((mfma_sums || mfma_pairs) && al) ? rows - rows % FUSED_TILE_ROWS : 0;
+    const uint64_t s0 = (mfma_sums || (mfma_pairs && !do_s)) ? body0 : 0, p0 = mfma_pairs ? body0 : 0;
+    if (std::min(s0, p0) != 0) { *missed = true; return COFACTOR_OK; }    // (the one-hot kernels would meet raw keys)
+  }
+  {
+    cofactor_status es = make_events();
+    if (es != COFACTOR_OK) return es;
   }
   if (e0) HIP_TRY(hipEventRecord(e0, st));
   for (uint64_t off = 0; off < rows; off += piece) {
@@ -425,7 +446,11 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
     // ---- keys -> 16-bit codes for the rows the code-cache kernels handle ----
     const uint64_t c_from = std::min(s_from, p_from);
     cofactor_status s = COFACTOR_OK;
-    if (missed && c_from != 0) { *missed = true; return COFACTOR_OK; }     // (the one-hot kernels would meet raw keys)
+    if (missed && c_from != 0) {                     // (ruled out above; kept as a guard)
+      if (e1) HIP_TRY(hipEventRecord(e1, st));
+      *missed = true;
+      return COFACTOR_OK;
+    }
     if (c_from < prows) {
       s = scratch_reserve(ctx, ctx->code_cache, ctx->code_cache_bytes, (size_t)L.m * stride * 2);
       if (s != COFACTOR_OK) return s;
@@ -438,7 +463,11 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
         int32_t miss = 0;
         HIP_TRY(hipMemcpyAsync(&miss, a->D.flags + 3, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (miss) { *missed = true; return COFACTOR_OK; }
+        if (miss) {
+          if (e1) HIP_TRY(hipEventRecord(e1, st));   // (the pair stays valid: it timed the translation)
+          *missed = true;
+          return COFACTOR_OK;
+        }
       }
     }
     if (body) {
@@ -1245,6 +1274,7 @@ cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms, ui
     for (auto &p : evs) {
       float t = 0;
       if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) total += t;
+      else (void)hipGetLastError();                 // (an unrecorded pair must not leave a sticky error behind)
       (void)hipEventDestroy(p.first);
       (void)hipEventDestroy(p.second);
     }
