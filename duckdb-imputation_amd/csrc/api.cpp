@@ -757,7 +757,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       if (missed) {                                 // a new key (or a route without the check): dictionary pass, then again
         s = cat_dictionaries(a, tcat, trows);
         if (s != COFACTOR_OK) return s;
-        s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/false, mask ? mask + done : nullptr);
+        s = cat_accumulate(a, tnum, tcat, trows, /*timed=*/!fused, mask ? mask + done : nullptr);
         if (s != COFACTOR_OK) return s;
       }
     }
