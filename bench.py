@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--rehearse-dist", action="store_true", help="run the multi-GPU code path at the current world size")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="functional rehearsal of N > 1 on a one-GPU box: every rank on cuda:0, gloo instead of "
+                         "RCCL (which refuses two ranks on one device); numbers mean nothing")
     return ap.parse_args()
 
 
@@ -136,6 +139,8 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py --gpus %d needs WORLD_SIZE=%d (got %d): launch it with torch.distributed.run "
                  "--nproc-per-node %d" % (args.gpus, args.gpus, world, args.gpus))
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # --rehearse-dist: take the N > 1 code path (RCCL process group, all-reduce of the partial
@@ -146,7 +151,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     scaling = args.scaling or ("weak" if args.rows is not None else "strong")
     if scaling == "weak":
@@ -191,7 +199,7 @@ def main():
     ctx.profile(False)
 
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -204,6 +212,8 @@ def main():
         pairs = [(j, j) for j in range(n)] + [(j, (j + 1 + j % 3) % n) for j in range(n) if n > 1]
         pairs = [(min(j, k), max(j, k)) for j, k in pairs]
         lin_ref, quad_ref = reference_sums(torch, num, pairs)
+        if use_dist and args.rehearse_one_gpu:
+            lin_ref, quad_ref = lin_ref.cpu(), quad_ref.cpu()
         if use_dist:
             dist.all_reduce(lin_ref)
             dist.all_reduce(quad_ref)
