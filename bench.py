@@ -10,8 +10,15 @@ seed 42, uniform [0,1) float32 columns, so that every sharding is the SAME table
 resident in HBM when the timed region starts.
 
     python bench.py                       # N = 1: 1e9 rows x 20 float columns (80 GB in HBM)
+    python bench.py --gpus N              # N > 1 from a plain shell: starts its own N ranks (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before this
+process has imported torch or made any HIP call (a process that has touched the GPU must never be
+replaced or forked), relays the ranks' output — rank 0's one JSON line — and exits with the
+child's return code.
 
 N > 1 is BASELINE.json's configs[3] — the SAME 1e9-row table sharded over the ranks ("scaling":
 "strong"); `--scaling weak` gives every rank `--rows` rows instead.  After the timed loop the
@@ -124,8 +131,30 @@ def reference_sums(torch, num, pairs):
     return lin, quad
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a plain shell: start one rank per GPU with
+    torch.distributed.run as a child process and relay its output and return code.  Nothing in
+    this process has touched the GPU (torch is not even imported here)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it here
+    env.setdefault("OMP_NUM_THREADS", "8")
+    if os.environ.get("BENCH_LAUNCH_DRY_RUN"):             # tests: show the command, start nothing
+        print(json.dumps({"launch": cmd}))
+        return 0
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     import torch
     import torch.distributed as dist
 
