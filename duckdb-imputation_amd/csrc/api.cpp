@@ -625,12 +625,20 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
   const uint64_t main_rows = rows - rows % FUSED_TILE_ROWS;
   // which one-pass kernel: fused_kernel (three teams, LDS-atomic pair counts) where it applies,
   // fused2_kernel (LDS-DMA ring, everything on MFMA) for what it does not take: NB aggregates, n = 0
-  bool v1 = false;
+  // fused3_kernel (the same ring with specialised pair / sum waves, two per SIMD) for the triple kind
+  // with n >= 1 and m >= 2
+  bool v1 = false, v3 = false;
   auto fused_fits = [&]() {
-    const bool ok1 = ctx->fused_pref != 2 && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
-    const bool ok2 = ctx->fused_pref != 1 && fused2_applicable(a->L, a->nkeys_host, mask != nullptr, ctx->lds_max);
+    const int pref = ctx->fused_pref;
+    // measured (tests/tools/onepass_compare.py, 5e7 rows): fused3 wins from 8 key columns on (10_10: 1.78 vs
+    // 1.83 ms, 2_10: 1.25 vs 1.58), fused_kernel below (10_4: 1.06 vs 1.18); COFACTOR_FUSED=3 pins it
+    const bool ok3 = (pref == 3 || (pref == 0 && a->m >= 8)) &&
+                     fused3_applicable(a->L, a->nkeys_host, mask != nullptr, ctx->lds_max);
+    const bool ok1 = !ok3 && pref != 2 && fused_applicable(a->L, a->nkeys_host, ctx->lds_max, nullptr);
+    const bool ok2 = pref != 1 && fused2_applicable(a->L, a->nkeys_host, mask != nullptr, ctx->lds_max);
+    v3 = ok3;
     v1 = ok1;
-    return ok1 || ok2;
+    return ok1 || ok2 || ok3;
   };
 
   // Optimistic mode: when every column already has a dictionary that fits the fused kernel, skip
@@ -673,7 +681,8 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       HIP_TRY(hipEventCreate(&e1));
       ctx->fused_ev.emplace_back(e0, e1);
     }
-    const int grid = v1 ? fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows)
+    const int grid = v3 ? fused2_grid(ctx->cus, ctx->gram_grid, main_rows, 1)
+                   : v1 ? fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows)
                         : fused2_grid(ctx->cus, ctx->gram_grid, main_rows,
                                       fused2_wgs_per_cu(a->L, mask != nullptr, ctx->lds_max));
     {
@@ -694,7 +703,10 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       skip = ctx->skip;
       HIP_TRY(hipMemsetAsync(skip, 0, sizeof(unsigned), st));
     }
-    if (v1)
+    if (v3)
+      HIP_TRY(launch_fused3(num, cat, main_rows, a->L, a->D, grid, ctx->lds_max, ctx->partials, ctx->pair_slabs,
+                            skip, a->d_acc, st, e0, e1, mask, a->d_kept));
+    else if (v1)
       HIP_TRY(launch_fused(num, cat, main_rows, a->L, a->D, grid, ctx->partials, ctx->pair_slabs, skip,
                            a->d_acc, st, e0, e1, mask, a->d_kept));
     else

@@ -248,6 +248,17 @@ hipError_t launch_fused2(const NumCols &num, const CatCols &cat, uint64_t rows, 
                          unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
                          hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr,
                          unsigned long long *kept = nullptr);
+// ---- fused3.hip: the same one pass with specialised waves, two per SIMD (pair waves / sum waves);
+// triple kind, n >= 1, 2 <= m <= 10, <= 16 keys per column.  Same contract as launch_fused2
+// (skip list in FUSED2_SKIP_UNIT rows, per-workgroup pair slabs, Gram partials). -----------------------
+bool fused3_applicable(const CatLayout &L, const int32_t *nkeys, bool masked, size_t lds_limit);
+hipError_t launch_fused3(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L,
+                         const CatDevice &D, int grid, size_t lds_limit, double *partials, unsigned *pair_slabs,
+                         unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
+                         hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr,
+                         unsigned long long *kept = nullptr);
+// D.p[cell] += sum over the workgroups' slabs (fused2.hip)
+hipError_t launch_pairs_fold2(const unsigned *slabs, int nwg, int n_p, unsigned long long *p, hipStream_t stream);
 hipError_t launch_gather_units(const NumCols &num, const CatCols &cat, int n, int m, int unit, const unsigned *list,
                                unsigned count, unsigned *temp, uint64_t temp_stride, hipStream_t stream,
                                const uint8_t *mask = nullptr, uint8_t *temp_mask = nullptr);

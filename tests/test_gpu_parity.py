@@ -645,7 +645,7 @@ def test_table_seam_alignment_and_roundtrip(ctx, n, m, nb, keys):
     agg.close()
 
 
-@pytest.mark.parametrize("pref", ["1", "2"])
+@pytest.mark.parametrize("pref", ["1", "2", "3"])
 @pytest.mark.parametrize("n,m,nb,keys", [(10, 10, False, 16), (3, 2, False, 7), (0, 3, False, 16), (5, 1, False, 3),
                                           (20, 4, False, 9), (12, 7, False, 16), (16, 6, False, 12), (4, 3, True, 16),
                                           (0, 2, True, 5), (20, 10, True, 16), (7, 9, False, 2)])
