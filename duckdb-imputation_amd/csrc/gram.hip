@@ -346,6 +346,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(NumCols cols, uint64
 // COFACTOR_GRAM_DMA=1 (tests/test_gpu_fullsize.py runs it).
 typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int DMA_COLB = 1040;                   // bytes of one column in a ring slot: 1 KiB + 16 (bank spread)
+constexpr int GRAM_RING_MIN_N = 99;              // gram_ring_kernel would be the default from this many columns on (nowhere: see its header)
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
   // (as an asm statement: the builtin makes hipcc wait vmcnt(0) before the next LDS access, i.e.
@@ -483,6 +484,185 @@ __global__ __launch_bounds__(64 * WAVES) void gram_dma_kernel(NumCols cols, uint
       }
     partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
   }
+}
+
+// ---- gram_ring_kernel: LDS-DMA ring with DEDICATED loader waves (default for whole tiles of aligned,
+// unfiltered columns) ------------------------------------------------------------------------------------
+// gram_dma_kernel's waves both load and compute, so a wave that is late in its MFMAs is late
+// with its next DMA and the bytes in flight sag; measured, that kernel needs three workgroups per CU to
+// reach gram_kernel's 6.0 TB/s whatever the ring depth.  Here ONE 512-thread workgroup per CU has
+//   waves 0-3: loaders — wait (counted vmcnt), barrier, issue the DMAs of the tile `ring - 1` ahead
+//              (wave-uniform 64-bit base in SGPRs + one lane-offset VGPR), nothing else;
+//   waves 4-7: the Gram of 64 rows each, straight from the raw tile (operand reads issued in batches
+//              before their MFMAs: a lone wave hides no LDS latency);
+// a loader and a compute wave share each SIMD.  ring - 1 tiles (up to 125 KB at n = 20) stay in
+// flight whatever the compute waves do.
+// Measured (20_0, 1e9 rows, round 3): the ring ALONE (compute waves idle, COFACTOR_GRAM_RING_ABLATE=1)
+// streams 6.75 TB/s = 84 % of the 8 TB/s peak at every depth 3..8; with the compute waves 5.9-6.3 TB/s,
+// again at every depth, i.e. the same as gram_kernel (6.0-6.2 on the same box) — the bytes in flight
+// are not what limits either kernel; the 128 KB of ds_read_b128 operand reads per 20 KB tile beside
+// the DMA writes are the suspect.  Narrow tables lose (n = 4: 5.0 vs 6.2 TB/s: 4 KB tiles, one
+// barrier each).  Opt-in: COFACTOR_GRAM_RING=1 (tests/test_gpu_fullsize.py runs it).
+__device__ __forceinline__ void dma16_s(const void *sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int N>
+__global__ __launch_bounds__(512) void gram_ring_kernel(NumCols cols, uint64_t nfull, double *__restrict__ partials,
+                                                        int ring, int ablate) {
+  constexpr int NB = (N + 3) / 4;
+  constexpr int NPAIR = NB * (NB + 1) / 2;
+  constexpr int RPM = gram_rows_per_mfma(N);
+  constexpr int SLOT = N * DMA_COLB;
+  constexpr int MAXCPW = (N + 3) / 4;
+  constexpr int RW = 64;                                     // rows of a tile per compute wave
+  static_assert(RW >= 4 * RPM, "a wave needs at least one full round of row groups");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dlds[];   // [ring][SLOT] | zero column
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave < 4;
+  const int sw = wave & 3;
+  unsigned char *zero = dlds + ring * SLOT;
+  for (int i = tid; i < DMA_COLB / 4; i += 512) reinterpret_cast<unsigned *>(zero)[i] = 0u;
+  __syncthreads();                                           // zero column written
+  const uint64_t G = gridDim.x;
+
+  if (loader) {
+    // this wave's columns: sw, sw + 4, ... (< N); its waits count its own DMA instructions
+    const int cpw = sw < N ? (N - sw + 3) / 4 : 0;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void_t *)dlds;
+    const unsigned lane16 = 16u * lane;
+    const unsigned char *src[MAXCPW];
+#pragma unroll
+    for (int i = 0; i < MAXCPW; i++) src[i] = reinterpret_cast<const unsigned char *>(cols.p[min(sw + 4 * i, N - 1)]);
+    auto dma_tile = [&](uint64_t t, int slot) {
+      const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT);
+#pragma unroll
+      for (int i = 0; i < MAXCPW; i++)
+        if (i < cpw) dma16_s(src[i] + t * (GRAM_TILE_ROWS * 4), lane16, __builtin_amdgcn_readfirstlane(base + (sw + 4 * i) * DMA_COLB));
+    };
+    uint64_t t = blockIdx.x;                                 // (blockIdx.x < nfull: the launcher sizes the grid)
+    for (int r = 0; r < ring - 1; r++) dma_tile(min(t + r * G, nfull - 1), r);
+    int slot = 0;
+    const int keep = (ring - 2) * cpw;                       // DMA instructions that may stay in flight at the wait
+    for (; t < nfull; t += G) {
+      dma_wait(keep);                                        // this wave's part of tile t has landed ...
+      __builtin_amdgcn_s_barrier();                          // ... and so has everybody else's; slot - 1 is free
+      int nslot = slot + ring - 1;
+      nslot = nslot >= ring ? nslot - ring : nslot;
+      dma_tile(min(t + (uint64_t)(ring - 1) * G, nfull - 1), nslot);      // past the end: a harmless re-load
+      slot = slot + 1 == ring ? 0 : slot + 1;
+    }
+    dma_wait_imm<0>();                                       // drain the re-loads before the ring is reused
+    __syncthreads();
+    __syncthreads();
+  } else {
+    int colA = -1, colB = -1, rsub = 0;
+    {
+      const int b = lane >> 2, tt = lane & 3;
+      if (b < RPM * NPAIR) {
+        rsub = b / NPAIR;
+        int bi = 0, rem = b % NPAIR;
+        while (rem >= NB - bi) { rem -= NB - bi; bi++; }
+        colA = 4 * bi + tt;
+        colB = 4 * (bi + rem) + tt;
+      }
+    }
+    const bool okA = colA >= 0 && colA < N, okB = colB >= 0 && colB < N;   // else: the zero column
+    const int g_row = (sw * RW + 4 * rsub) * 4;
+    const int offA = colA * DMA_COLB + g_row, offB = colB * DMA_COLB + g_row;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    f32x2 ls_lo = {0.f, 0.f}, ls_hi = {0.f, 0.f};
+    double dq0 = 0, dq1 = 0, dq2 = 0, dq3 = 0, dl = 0;
+    int since_flush = 0;
+    auto flush = [&]() {
+      dq0 += (double)((acc0[0] + acc1[0]) + (acc2[0] + acc3[0]));
+      dq1 += (double)((acc0[1] + acc1[1]) + (acc2[1] + acc3[1]));
+      dq2 += (double)((acc0[2] + acc1[2]) + (acc2[2] + acc3[2]));
+      dq3 += (double)((acc0[3] + acc1[3]) + (acc2[3] + acc3[3]));
+      dl += (double)((ls_lo[0] + ls_lo[1]) + (ls_hi[0] + ls_hi[1]));
+      acc0 = acc1 = acc2 = acc3 = f32x4{0, 0, 0, 0};
+      ls_lo = ls_hi = f32x2{0.f, 0.f};
+    };
+    int slot = 0;
+    for (uint64_t t = blockIdx.x; t < nfull; t += G) {
+      __builtin_amdgcn_s_barrier();                          // tile t is in `slot`
+      if (ablate) { slot = slot + 1 == ring ? 0 : slot + 1; continue; }   // (probe: the bare ring, tests/tools)
+      const unsigned char *base = dlds + slot * SLOT;
+      const f32x4 *va = reinterpret_cast<const f32x4 *>(okA ? base + offA : zero + g_row);
+      const f32x4 *vb = reinterpret_cast<const f32x4 *>(okB ? base + offB : zero + g_row);
+      // every operand read of the wave's 64 rows is issued up front (<= 128 registers, the wave has 256):
+      // one exposed LDS latency per tile, then the MFMAs run as the reads arrive
+      constexpr int GIT = RW / 4 / RPM, GBT = GIT;
+#pragma unroll
+      for (int it0 = 0; it0 < GIT; it0 += GBT) {
+        f32x4 ga[GBT], gb[GBT];
+#pragma unroll
+        for (int it = 0; it < GBT; it++) { ga[it] = va[(it0 + it) * RPM]; gb[it] = vb[(it0 + it) * RPM]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < GBT; it++) {
+          const f32x4 a = ga[it], b = gb[it];
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc3, 0, 0, 0);
+          ls_lo += __builtin_shufflevector(a, a, 0, 1);
+          ls_hi += __builtin_shufflevector(a, a, 2, 3);
+        }
+      }
+      if (++since_flush == FLUSH_TILES * RPM) { flush(); since_flush = 0; }
+      slot = slot + 1 == ring ? 0 : slot + 1;
+    }
+    flush();
+    __syncthreads();                                         // (the loaders' drain: the ring is free)
+    double *mine = reinterpret_cast<double *>(dlds) + sw * GRAM_ACC_LEN;
+    mine[0 * 64 + lane] = dq0;
+    mine[1 * 64 + lane] = dq1;
+    mine[2 * 64 + lane] = dq2;
+    mine[3 * 64 + lane] = dq3;
+    mine[4 * 64 + lane] = dl;
+    __syncthreads();
+  }
+  const double *red = reinterpret_cast<const double *>(dlds);   // 4 x 320 doubles
+  for (int i = tid; i < GRAM_ACC_LEN; i += 512) {
+    const int ln = i & 63;
+    double v = 0;
+    if (ln < 4 * NPAIR)
+#pragma unroll
+      for (int rs = 0; rs < RPM; rs++) {
+        const int j = i + 4 * NPAIR * rs;
+#pragma unroll
+        for (int w = 0; w < 4; w++) v += red[w * GRAM_ACC_LEN + j];     // fixed order
+      }
+    partials[(uint64_t)i * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+// ring depth of gram_ring_kernel for n columns: as deep as 150 KB of LDS allow, at most 8 slots and
+// at most 40 DMA instructions per loader in flight (the waits are immediates)
+static int gram_ring_depth(int n, size_t &lds) {
+  static const int env_ring = [] { const char *v = getenv("COFACTOR_GRAM_RING_DEPTH"); return v ? atoi(v) : 0; }();
+  const size_t slot = (size_t)n * DMA_COLB;
+  const int cpw = (n + 3) / 4;
+  int ring = 3;
+  while (ring < 8 && (size_t)(ring + 1) * slot + DMA_COLB <= 150 * 1024 && (ring - 1) * cpw <= 40) ring++;
+  if (env_ring >= 2 && env_ring <= ring) ring = env_ring;
+  lds = std::max((size_t)ring * slot + DMA_COLB, sizeof(double) * 4 * GRAM_ACC_LEN);
+  return ring;
+}
+
+template <int N>
+static hipError_t launch_ring_n(const NumCols &cols, uint64_t nfull, int grid, size_t lds, int ring, double *partials,
+                                hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute((const void *)gram_ring_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  static const int ablate = [] { const char *v = getenv("COFACTOR_GRAM_RING_ABLATE"); return v ? atoi(v) : 0; }();
+  hipLaunchKernelGGL((gram_ring_kernel<N>), dim3(grid), dim3(512), lds, stream, cols, nfull, partials, ring, ablate);
+  return hipGetLastError();
 }
 
 // shape of the DMA kernel for n columns: waves per workgroup, ring depth, workgroups per CU (160 KB
@@ -646,8 +826,41 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
   if (rrows == 0) return ev1 ? hipEventRecord(ev1, stream) : hipSuccess;
   // COFACTOR_GRAM_DMA=1: whole tiles of aligned, unfiltered columns through the LDS-DMA variant
   // (measured equal to gram_kernel, 13.4 vs 13.5 ms per 1e9 rows at n = 20: off by default)
-  const char *dma_env = getenv("COFACTOR_GRAM_DMA");
-  const int use_dma = dma_env ? atoi(dma_env) : 0;
+  // gram_ring_kernel (dedicated loader waves): COFACTOR_GRAM_RING=0 switches it off, =1 forces it for
+  // every n; by default it takes the column counts it was measured faster for (g_ring_min_n and up)
+  static const int ring_env = [] { const char *v = getenv("COFACTOR_GRAM_RING"); return v ? atoi(v) : -1; }();
+  static const int dma_env_v = [] { const char *v = getenv("COFACTOR_GRAM_DMA"); return v ? atoi(v) : 0; }();
+  const bool want_ring = ring_env == 1 || (ring_env != 0 && !dma_env_v && n >= GRAM_RING_MIN_N);
+  if (want_ring && !mask && rrows >= 1024 * (uint64_t)GRAM_TILE_ROWS) {
+    bool aligned = true;
+    for (int k = 0; k < n; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(rest.p[k]) & 15) == 0);
+    if (aligned) {
+      const uint64_t nfull = rrows / GRAM_TILE_ROWS;
+      size_t lds;
+      const int ring = gram_ring_depth(n, lds);
+      static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+      int dgrid = std::min(grid, cus);
+      if ((uint64_t)dgrid > nfull) dgrid = (int)nfull;
+      e = hipErrorInvalidValue;
+      switch (n) {
+#define CASE(N) case N: e = launch_ring_n<N>(rest, nfull, dgrid, lds, ring, partials, stream); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+        CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
+#undef CASE
+        default: break;
+      }
+      if (e != hipSuccess) return e;
+      const uint64_t done = nfull * GRAM_TILE_ROWS;
+      if (done == rrows) {
+        if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
+        return launch_gram_fold(partials, dgrid, acc, stream);
+      }
+      if ((e = launch_gram_fold(partials, dgrid, acc, stream)) != hipSuccess) return e;
+      for (int k = 0; k < n; k++) rest.p[k] += done;
+      rrows -= done;
+    }
+  }
+  const int use_dma = dma_env_v;
   if (use_dma && !mask && rrows >= 64 * (uint64_t)GRAM_TILE_ROWS) {
     bool aligned = true;
     for (int k = 0; k < n; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(rest.p[k]) & 15) == 0);

@@ -124,12 +124,14 @@ def test_10_10_thousand_keys_per_column_exact(ctx):
             q += 1
 
 
+@pytest.mark.parametrize("env", ["COFACTOR_GRAM_DMA", "COFACTOR_GRAM_RING"])
 @pytest.mark.parametrize("n", [1, 4, 7, 12, 13, 20])
-def test_lds_dma_variant_of_the_dense_kernel_is_exact(monkeypatch, n):
+def test_lds_dma_variant_of_the_dense_kernel_is_exact(monkeypatch, n, env):
     """COFACTOR_GRAM_DMA=1 sends whole tiles through gram_dma_kernel (tiles fetched by LDS-DMA, 4 or 8
-    waves per tile), the tail through gram_kernel: same integer-valued table, same exact sums."""
+    waves per tile), COFACTOR_GRAM_RING=1 through gram_ring_kernel (dedicated loader waves), the tail
+    through gram_kernel: same integer-valued table, same exact sums."""
     import torch
-    monkeypatch.setenv("COFACTOR_GRAM_DMA", "1")
+    monkeypatch.setenv(env, "1")
     c = cofactor_hip.Context(0)
     rows = 3_000_000 + 77
     g = torch.Generator(device="cuda").manual_seed(300 + n)
