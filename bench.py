@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-calibration", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--rehearse-dist", action="store_true", help="run the multi-GPU code path at the current world size")
+    ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
+                    help="N > 1: the library's own RCCL communicator below the C ABI (cofactor_agg_allreduce) or "
+                         "torch.distributed's all_reduce on the exported buffer")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="functional rehearsal of N > 1 on a one-GPU box: every rank on cuda:0, gloo instead of "
                          "RCCL (which refuses two ranks on one device); numbers mean nothing")
@@ -199,12 +202,22 @@ def main():
     num_ptrs = [t.data_ptr() for t in num]
     cat_ptrs = [t.data_ptr() for t in cat]
     torch.cuda.synchronize()
+    # N > 1: the merge of the ranks' partial triples runs below the C ABI on the library's own RCCL
+    # communicator; torch.distributed is the rendezvous (it carries the 128-byte id), the barrier and
+    # the timing reduction.  (Two ranks on ONE device — the gloo rehearsal — cannot use RCCL.)
+    comm = None
+    collective = "none"
+    if use_dist:
+        collective = "torch.distributed all_reduce (%s)" % dist.get_backend()
+        if args.collective == "lib" and not args.rehearse_one_gpu:
+            comm = cdist.make_comm(ctx, dist)
+            collective = "cofactor_agg_allreduce: ncclAllReduce on the library's communicator (csrc/comm.cpp)"
 
     def step():
         agg.reset()
         agg.update_device_ptrs(num_ptrs, cat_ptrs, rows)
         if use_dist:
-            return cdist.allreduce_triple(agg, dist, device)     # ONE RCCL all-reduce, then finalize
+            return cdist.allreduce_triple(agg, dist, device, comm)     # ONE RCCL all-reduce, then finalize
         return agg.finalize()
 
     def fence():
@@ -306,13 +319,16 @@ def main():
                        "arithmetic": "f32 inputs and f32 MFMA products; f32 partial sums of at most 64 terms "
                                      "(dense) / 2048 bf16-piece terms (per-key sums) folded into f64; exact "
                                      "integer counts",
-                       "parallelism": "row-sharded x%d, one RCCL all-reduce of the partial triple" % world},
+                       "parallelism": "row-sharded x%d, one RCCL all-reduce of the partial triple" % world,
+                       "collective": collective},
             "roofline": roof,
             "check": check,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(num, cat, args.cpu_sample_rows, args.cpu_1t_sample_rows, n, m, args.nb)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

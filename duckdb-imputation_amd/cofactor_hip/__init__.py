@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTE
 
 # every symbol include/cofactor_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cofactor_last_error", "cofactor_abi_version",
+    "cofactor_last_error", "cofactor_abi_version", "cofactor_device_count",
     "cofactor_ctx_create", "cofactor_ctx_destroy", "cofactor_ctx_synchronize", "cofactor_ctx_stream",
     "cofactor_ctx_profile_enable", "cofactor_ctx_profile_read", "cofactor_ctx_calibrate",
     "cofactor_agg_create", "cofactor_agg_destroy", "cofactor_agg_reset",
@@ -27,6 +27,9 @@ SYMBOLS = [
     "cofactor_dense_len", "cofactor_agg_export_dense_device", "cofactor_agg_import_dense_device",
     "cofactor_agg_keys", "cofactor_agg_dict_signature", "cofactor_agg_align_keys",
     "cofactor_agg_tables_len", "cofactor_agg_export_tables_device", "cofactor_agg_import_tables_device",
+    "cofactor_agg_sparse_lens", "cofactor_agg_sparse_is_list", "cofactor_agg_sparse_export_device",
+    "cofactor_agg_sparse_assign_device",
+    "cofactor_comm_unique_id", "cofactor_comm_create", "cofactor_comm_destroy", "cofactor_agg_allreduce",
     "cofactor_lift_host", "cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub",
     "cofactor_lift_device", "cofactor_agg_update_tvec_device", "cofactor_multiply_device",
     "cofactor_lift_host_tvec", "cofactor_agg_update_tvec_host", "cofactor_multiply_host",
@@ -94,6 +97,15 @@ def lib():
         L.cofactor_agg_tables_len.restype = u64
         L.cofactor_agg_export_tables_device.argtypes = [vp, vp]
         L.cofactor_agg_import_tables_device.argtypes = [vp, vp]
+        L.cofactor_agg_sparse_lens.argtypes = [vp, pu64, u64]
+        L.cofactor_agg_sparse_is_list.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
+        L.cofactor_agg_sparse_export_device.argtypes = [vp, C.c_int32, vp, vp]
+        L.cofactor_agg_sparse_assign_device.argtypes = [vp, C.c_int32, vp, vp, u64]
+        L.cofactor_comm_unique_id.argtypes = [vp]
+        L.cofactor_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, pp]
+        L.cofactor_comm_destroy.argtypes = [vp]
+        L.cofactor_comm_destroy.restype = None
+        L.cofactor_agg_allreduce.argtypes = [vp, vp]
         L.cofactor_lift_host.argtypes = [pp, C.c_int, pp, C.c_int, u64, C.c_int, vp, u64, pu64, vp]
         for f in ("cofactor_triple_multiply", "cofactor_triple_add", "cofactor_triple_sub"):
             getattr(L, f).argtypes = [vp, u64, vp, u64, vp, u64, pu64]
@@ -389,6 +401,60 @@ class Aggregate:
 
     def import_tables_device(self, ptr):
         _check(lib().cofactor_agg_import_tables_device(self._h, ptr))
+
+    # ---- pair tables kept as sorted lists (very high cardinalities) across ranks ----
+    def sparse_lens(self):
+        """-> uint64[m(m+1)/2]: entries of every pair's sorted list (0 for dense pair tables)."""
+        np_ = self.m * (self.m + 1) // 2
+        out = np.zeros(max(1, np_), dtype=np.uint64)
+        _check(lib().cofactor_agg_sparse_lens(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
+        return out[:np_]
+
+    def sparse_is_list(self, pair):
+        v = C.c_int32(0)
+        _check(lib().cofactor_agg_sparse_is_list(self._h, pair, C.byref(v)))
+        return bool(v.value)
+
+    def sparse_export_device(self, pair, keys_ptr, counts_ptr):
+        _check(lib().cofactor_agg_sparse_export_device(self._h, pair, keys_ptr, counts_ptr))
+
+    def sparse_assign_device(self, pair, keys_ptr, counts_ptr, length):
+        _check(lib().cofactor_agg_sparse_assign_device(self._h, pair, keys_ptr, counts_ptr, length))
+
+    def allreduce(self, comm):
+        """The whole multi-GPU seam below the C ABI (cofactor_agg_allreduce): afterwards this state is
+        the merge of all ranks' states."""
+        _check(lib().cofactor_agg_allreduce(self._h, comm._h))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes rank 0 hands to the other ranks (cofactor_comm_unique_id)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().cofactor_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """The library's own RCCL communicator of one rank (cofactor_comm)."""
+
+    def __init__(self, ctx, uid, rank, world):
+        assert len(uid) == COMM_ID_BYTES
+        h = C.c_void_p()
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(lib().cofactor_comm_create(ctx._h, buf, rank, world, C.byref(h)))
+        self._h, self.ctx, self.rank, self.world = h, ctx, rank, world
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().cofactor_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        if lib is not None:
+            self.close()
 
 
 def lift_host(num_cols, cat_cols, kind=TRIPLE):

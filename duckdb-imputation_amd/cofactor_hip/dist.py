@@ -16,6 +16,10 @@ table) a step is one small all-gather and one all-reduce.
 
 Backends: "nccl" (= RCCL) on GPUs.  "gloo" stages the buffer through host memory — that is how the
 world-size-2 tests run two ranks on one GPU.
+
+The same seam exists BELOW the C ABI (cofactor_comm_* / cofactor_agg_allreduce, csrc/comm.cpp: the
+library's own RCCL communicator, no torch in the data path): `make_comm` + `allreduce_state(...,
+comm=comm)`.  torch.distributed is then only the rendezvous that ships the 128-byte id.
 """
 import numpy as np
 
@@ -29,8 +33,12 @@ def _seam_buffer(agg, length, device):
     """Persistent device buffer of the aggregate (never handed back to torch's allocator while
     kernels of the library's stream may still read it)."""
     import torch
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:        # 'cuda' never equals 'cuda:0': the buffer
+        device = torch.device("cuda", torch.cuda.current_device())   # would be re-made on every call
     buf = getattr(agg, "_seam_buf", None)
-    if buf is None or buf.numel() < length or buf.device != torch.device(device):
+    if buf is None or buf.numel() < length or buf.device != device:
+        agg.ctx.synchronize()                       # (the import kernel of the last step may still read the old one)
         buf = torch.empty(max(256, int(length)), dtype=torch.float64, device=device)
         agg._seam_buf = buf
     return buf[:length]
@@ -93,15 +101,68 @@ def align_dictionaries(agg, dist, comm_device):
     return True
 
 
-def allreduce_state(agg, dist, device):
-    """In place: the aggregate becomes the merge of all ranks' aggregates (dense totals and, after
-    dictionary alignment, every categorical table).  One all-reduce."""
+def make_comm(ctx, dist):
+    """The library's own communicator for this rank: rank 0 makes the id, torch.distributed (any
+    backend) only carries its 128 bytes to the other ranks."""
+    import cofactor_hip
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [cofactor_hip.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return cofactor_hip.Comm(ctx, box[0], rank, world)
+
+
+def _gather_sparse_lists(agg, dist, device, comm_device):
+    """Pair tables kept as sorted lists: every rank gathers all ranks' lists and merges them
+    (cofactor_agg_sparse_*; the torch / gloo flavour of step 4 of cofactor_agg_allreduce)."""
     import torch
+    if agg.m == 0 or agg.kind != 0:
+        return
+    lens = agg.sparse_lens().astype(np.int64)
+    all_lens = _gather_int64(lens, dist, comm_device)
+    for q in range(lens.size):
+        total = int(sum(int(l[q]) for l in all_lens))
+        if total == 0:
+            continue
+        longest = int(max(int(l[q]) for l in all_lens))
+        mine = torch.zeros(2 * longest, dtype=torch.int64, device=device)
+        torch.cuda.current_stream(mine.device).synchronize()
+        agg.sparse_export_device(q, mine.data_ptr(), mine.data_ptr() + 8 * longest)
+        agg.ctx.synchronize()
+        send = mine.to(comm_device)
+        got = [torch.empty_like(send) for _ in range(dist.get_world_size())]
+        dist.all_gather(got, send)
+        keys = torch.cat([g[:int(l[q])] for g, l in zip(got, all_lens)]).to(device)
+        cnts = torch.cat([g[longest:longest + int(l[q])] for g, l in zip(got, all_lens)]).to(device)
+        torch.cuda.current_stream(keys.device).synchronize()
+        agg.sparse_assign_device(q, keys.data_ptr(), cnts.data_ptr(), total)
+
+
+def allreduce_state(agg, dist, device, comm=None):
+    """In place: the aggregate becomes the merge of all ranks' aggregates (dense totals and, after
+    dictionary alignment, every categorical table).  One all-reduce.  With `comm` (make_comm) the
+    whole seam runs below the C ABI on the library's own RCCL communicator."""
+    import torch
+    if comm is not None:
+        agg.allreduce(comm)
+        return
     backend = dist.get_backend()
     on_gpu = torch.device(device).type == "cuda"
     comm_device = device if (backend == "nccl" and on_gpu) else "cpu"
-    align_dictionaries(agg, dist, comm_device)
-    dlen, tlen = int(agg.dense_len()), int(agg.tables_len())
+    # a rank that fails while preparing must not leave the others inside the collective: the ranks
+    # exchange a status word (and the buffer length) first and raise together
+    err = None
+    try:
+        align_dictionaries(agg, dist, comm_device)
+        dlen, tlen = int(agg.dense_len()), int(agg.tables_len())
+    except Exception as e:                          # noqa: BLE001 - reported on every rank below
+        err, dlen, tlen = e, 0, 0
+    got = _gather_int64(np.array([0 if err is None else 1, dlen + tlen], dtype=np.int64), dist, comm_device)
+    bad = [r for r, g in enumerate(got) if int(g[0]) != 0]
+    if bad:
+        raise RuntimeError("allreduce_state: rank(s) %s could not prepare their state%s" %
+                           (bad, "" if err is None else ": %s" % err))
+    if len({int(g[1]) for g in got}) != 1:
+        raise RuntimeError("allreduce_state: the ranks' aligned images differ in length: %s" % [int(g[1]) for g in got])
     buf = _seam_buffer(agg, dlen + tlen, device)
     dptr = buf.data_ptr()
     if backend == "nccl":
@@ -125,6 +186,7 @@ def allreduce_state(agg, dist, device):
         agg.import_dense_device(dptr)
         if tlen:
             agg.import_tables_device(dptr + 8 * dlen)
+    _gather_sparse_lists(agg, dist, device, comm_device)
 
 
 def allreduce_dense(agg, dist, device):
@@ -133,9 +195,9 @@ def allreduce_dense(agg, dist, device):
     allreduce_state(agg, dist, device)
 
 
-def allreduce_triple(agg, dist, device):
+def allreduce_triple(agg, dist, device, comm=None):
     """The reduced triple (flat blob), identical on every rank."""
-    allreduce_state(agg, dist, device)
+    allreduce_state(agg, dist, device, comm)
     return agg.finalize()
 
 

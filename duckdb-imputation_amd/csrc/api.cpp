@@ -1204,6 +1204,10 @@ extern "C" {
 
 const char *cofactor_last_error(void) { return g_err.c_str(); }
 int cofactor_abi_version(void) { return COFACTOR_ABI_VERSION; }
+int cofactor_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   if (!out) return fail(COFACTOR_ERR_INVALID, "out is null");
@@ -1512,20 +1516,6 @@ cofactor_status cofactor_agg_update_triples(cofactor_agg *a, const double *blobs
   return COFACTOR_OK;
 }
 
-cofactor_status cofactor_agg_combine(cofactor_agg *dst, cofactor_agg *src) {
-  if (!dst || !src) return fail(COFACTOR_ERR_INVALID, "null argument");
-  if (dst == src) return fail(COFACTOR_ERR_INVALID, "combine of a state with itself");
-  if (dst->n != src->n || dst->m != src->m || dst->kind != src->kind)
-    return fail(COFACTOR_ERR_INVALID, "combine: state shapes differ");
-  HostTriple snap;
-  cofactor_status s = snapshot(src, snap);
-  if (s != COFACTOR_OK) return s;
-  std::string err;
-  dst->blob_cache_valid = false;
-  if (!dst->host.add(snap, err)) return fail(COFACTOR_ERR_INVALID, err);
-  return COFACTOR_OK;
-}
-
 cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap, uint64_t *needed) {
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
   CTX_LOCK(a->ctx);
@@ -1689,7 +1679,6 @@ cofactor_status cofactor_agg_align_keys(cofactor_agg *a, const int32_t *keys_in,
   if (s != COFACTOR_OK) return s;
   s = cat_prepare(a);
   if (s != COFACTOR_OK) return s;
-  if (any_sparse_pair(a->L)) return fail(COFACTOR_ERR_UNSUPPORTED, "the state holds sparse pair tables (very high cardinalities): the dictionary-aligned table exchange does not cover them; exchange finalised blobs instead");
   hipStream_t st = a->ctx->stream;
   // the global key lists: whatever was handed in (any order, duplicates allowed: the
   // concatenation of all ranks' lists), sorted and made unique here
@@ -1717,8 +1706,32 @@ cofactor_status cofactor_agg_align_keys(cofactor_agg *a, const int32_t *keys_in,
     Ln.kc[c] = std::max(16, next_pow2((int)G[c].size()));
     Ln.ht_cap[c] = std::max(64, next_pow2(2 * (int)G[c].size()));
   }
-  if (!cat_finish_layout(Ln))
+  // (pair tables too big to be dense stay / become sorted lists: they are keyed by the keys
+  // themselves, so alignment does not touch them)
+  if (!cat_finish_layout(Ln, /*allow_sparse=*/a->kind == COFACTOR_TRIPLE))
     return fail(COFACTOR_ERR_UNSUPPORTED, "categorical cardinalities too high for dense code-indexed pair tables");
+  if (any_sparse_pair(Ln)) a->sparse.resize(tri(a->m));
+  // a pair table that is dense now and sparse under the aligned layout moves into its store first
+  if (a->kind == COFACTOR_TRIPLE && any_sparse_pair(Ln) && a->dev_dirty) {
+    int32_t *key_of = nullptr;
+    hipError_t e2 = hipSuccess;
+    int q = 0;
+    for (int c1 = 0; c1 < a->m && e2 == hipSuccess; c1++)
+      for (int c2 = c1; c2 < a->m && e2 == hipSuccess; c2++, q++) {
+        if (!pair_is_sparse(Ln, q) || pair_is_sparse(Lo, q)) continue;
+        if (!key_of) {
+          e2 = hipMalloc((void **)&key_of, sizeof(int32_t) * std::max(1, Lo.n_cnt));
+          for (int c = 0; c < a->m && e2 == hipSuccess; c++)
+            e2 = launch_key_of_code(a->D.ht_slot + Lo.ht_off[c], a->D.ht_code + Lo.ht_off[c], Lo.ht_cap[c], Lo.kc[c],
+                                    key_of + Lo.cnt_off[c], st);
+        }
+        if (e2 == hipSuccess)
+          e2 = sparse_add_dense(a->ctx->sparse_sc, a->sparse[q], a->D.p + Lo.p_off[q], Lo.kc[c1], Lo.kc[c2],
+                                key_of + Lo.cnt_off[c1], key_of + Lo.cnt_off[c2], st);
+      }
+    if (key_of) { (void)hipStreamSynchronize(st); (void)hipFree(key_of); }
+    if (e2 != hipSuccess) return hip_fail(e2, "align_keys: dense -> sparse pair table");
+  }
   // aligned dictionary (code = rank of the key in the global list) and old code -> new code
   std::vector<unsigned long long> nslot(Ln.n_slots, 0ull);
   std::vector<int32_t> ncode(Ln.n_slots, -1), remap(std::max(1, Lo.n_cnt), -1);
@@ -1773,6 +1786,7 @@ cofactor_status cofactor_agg_align_keys(cofactor_agg *a, const int32_t *keys_in,
       for (int c1 = 0; c1 < a->m; c1++)
         for (int c2 = c1; c2 < a->m; c2++, q++)
           for (auto const &kv : a->host.pair[q]) {
+            if (pair_is_sparse(Ln, q)) continue;    // (merged into the pair's sorted store below)
             // a pair's keys are keys of their columns' lin_cat lists (same rows), hence in G
             const size_t k1 = code_of(c1, kv.first.first), k2 = code_of(c2, kv.first.second);
             if (k1 >= G[c1].size() || k2 >= G[c2].size() || G[c1][k1] != kv.first.first || G[c2][k2] != kv.first.second) {
@@ -1785,6 +1799,25 @@ cofactor_status cofactor_agg_align_keys(cofactor_agg *a, const int32_t *keys_in,
     if (e == hipSuccess) e = hipMalloc((void **)&d_add, sizeof(double) * addv.size());
     if (e == hipSuccess) e = hipMemcpyAsync(d_add, addv.data(), sizeof(double) * addv.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_cat_tables_import(Ln, Dn, d_add, /*add=*/true, st);
+    if (e == hipSuccess && !a->kind && any_sparse_pair(Ln)) {   // host-side entries of sparse pairs: into their stores
+      int q = 0;
+      for (int c1 = 0; c1 < a->m && e == hipSuccess; c1++)
+        for (int c2 = c1; c2 < a->m && e == hipSuccess; c2++, q++) {
+          if (!pair_is_sparse(Ln, q) || a->host.pair[q].empty()) continue;
+          std::vector<unsigned long long> hk, hv;
+          for (auto const &kv : a->host.pair[q]) {
+            hk.push_back(sparse_pack(kv.first.first, kv.first.second));
+            hv.push_back((unsigned long long)(kv.second + 0.5));
+          }
+          unsigned long long *dk = nullptr;
+          e = hipMalloc((void **)&dk, hk.size() * 16);
+          if (e == hipSuccess) e = hipMemcpyAsync(dk, hk.data(), hk.size() * 8, hipMemcpyHostToDevice, st);
+          if (e == hipSuccess) e = hipMemcpyAsync(dk + hk.size(), hv.data(), hk.size() * 8, hipMemcpyHostToDevice, st);
+          if (e == hipSuccess) e = sparse_merge_lists(a->ctx->sparse_sc, a->sparse[q], dk, dk + hk.size(), hk.size(), st);
+          (void)hipStreamSynchronize(st);
+          (void)hipFree(dk);
+        }
+    }
   }
   hipError_t es = hipStreamSynchronize(st);
   if (e == hipSuccess) e = es;
@@ -1823,7 +1856,6 @@ cofactor_status cofactor_agg_export_tables_device(cofactor_agg *a, double *d_out
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   if (a->stage_rows > 0) return fail(COFACTOR_ERR_INVALID, "export_tables: rows are still staged on the host (align first)");
-  if (any_sparse_pair(a->L)) return fail(COFACTOR_ERR_UNSUPPORTED, "the state holds sparse pair tables (very high cardinalities): the dictionary-aligned table exchange does not cover them; exchange finalised blobs instead");
   HIP_TRY(launch_cat_tables_export(a->L, a->D, d_out, a->ctx->stream));
   return COFACTOR_OK;
 }
@@ -1833,8 +1865,212 @@ cofactor_status cofactor_agg_import_tables_device(cofactor_agg *a, const double 
   if (a->m == 0 || !a->cat_ready) return COFACTOR_OK;
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
-  if (any_sparse_pair(a->L)) return fail(COFACTOR_ERR_UNSUPPORTED, "the state holds sparse pair tables (very high cardinalities): the dictionary-aligned table exchange does not cover them; exchange finalised blobs instead");
   HIP_TRY(launch_cat_tables_import(a->L, a->D, d_in, /*add=*/false, a->ctx->stream));
+  a->dev_dirty = true;
+  a->blob_cache_valid = false;
+  return COFACTOR_OK;
+}
+
+// ---- combine on the device (Triple::SumStateCombine, sum_state.cpp:10-114) ------------------------------
+// dst += src without a host round trip of the tables: the accumulator image is added by a kernel;
+// the two states' dictionaries are aligned to the union of their key lists (remap kernels; only the
+// key lists themselves, a few KB, pass through the host, and not even those while both states still
+// hold a common alignment), then the table image [cnt | s | p] of src is added into dst's by
+// export -> (peer copy when the states live on different GPUs) -> import(add); sorted pair lists
+// are merged (sort + reduce by key).  src keeps its value (its tables may be re-indexed).
+namespace {
+
+bool holds_host_keys(const cofactor_agg *a) {
+  for (auto const &c : a->host.col) if (!c.empty()) return true;
+  for (auto const &t : a->host.pair) if (!t.empty()) return true;
+  return false;
+}
+
+// bytes on `ddev` <- bytes on `sdev`, ordered on `st` (a stream of ddev)
+hipError_t copy_between(void *dst, int ddev, const void *src, int sdev, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  if (ddev == sdev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+  return hipMemcpyPeerAsync(dst, ddev, src, sdev, bytes, st);
+}
+
+}  // namespace
+
+cofactor_status cofactor_agg_combine(cofactor_agg *dst, cofactor_agg *src) {
+  if (!dst || !src) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (dst == src) return fail(COFACTOR_ERR_INVALID, "combine of a state with itself");
+  if (dst->n != src->n || dst->m != src->m || dst->kind != src->kind)
+    return fail(COFACTOR_ERR_INVALID, "combine: state shapes differ");
+  cofactor_ctx *cd = dst->ctx, *cs = src->ctx;
+  // both contexts, in address order (two threads combining a -> b and b -> a must not deadlock)
+  std::unique_lock<std::recursive_mutex> l1(cd < cs ? cd->mu : cs->mu);
+  std::unique_lock<std::recursive_mutex> l2;
+  if (cd != cs) l2 = std::unique_lock<std::recursive_mutex>(cd < cs ? cs->mu : cd->mu);
+  const int ddev = cd->device, sdev = cs->device;
+  dst->blob_cache_valid = false;
+  cofactor_status s;
+  { DeviceGuard g(sdev); if ((s = stage_flush(src)) != COFACTOR_OK) return s; }
+  { DeviceGuard g(ddev); if ((s = stage_flush(dst)) != COFACTOR_OK) return s; }
+  // what src holds on the host (earlier combines of host states, lifted triples): dense addends
+  // are added on the host, keys are folded into its device tables by the alignment below
+  dst->host.N += src->host.N;
+  for (size_t k = 0; k < dst->host.lin.size() && k < src->host.lin.size(); k++) dst->host.lin[k] += src->host.lin[k];
+  for (size_t k = 0; k < dst->host.quad.size() && k < src->host.quad.size(); k++) dst->host.quad[k] += src->host.quad[k];
+  const bool src_keys = src->m > 0 && ((src->cat_ready && src->dev_dirty) || holds_host_keys(src));
+  hipEvent_t ev = nullptr;
+  double *tmp_s = nullptr, *tmp_d = nullptr;
+  unsigned long long *sp_tmp = nullptr;
+  auto cleanup = [&]() {
+    if (ev) (void)hipEventDestroy(ev);
+    if (tmp_s) { DeviceGuard g(sdev); (void)hipFree(tmp_s); }
+    if (tmp_d && tmp_d != tmp_s) { DeviceGuard g(ddev); (void)hipFree(tmp_d); }
+    if (sp_tmp) { DeviceGuard g(ddev); (void)hipFree(sp_tmp); }
+  };
+#define COMBINE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return hip_fail(e_, #expr); } } while (0)
+  if (src_keys) {
+    // ---- dictionaries: same alignment already, or align both to the union of their key lists ----
+    uint64_t sig_s = 0, sig_d = 0;
+    (void)cofactor_agg_dict_signature(src, &sig_s);
+    (void)cofactor_agg_dict_signature(dst, &sig_d);
+    if (!(sig_s != 0 && sig_s == sig_d)) {
+      std::vector<std::vector<int32_t>> ks, kd;
+      { DeviceGuard g(sdev); if ((s = collect_keys(src, ks)) != COFACTOR_OK) { cleanup(); return s; } }
+      { DeviceGuard g(ddev); if ((s = collect_keys(dst, kd)) != COFACTOR_OK) { cleanup(); return s; } }
+      std::vector<int32_t> all;
+      std::vector<uint64_t> offs(dst->m + 1, 0);
+      for (int c = 0; c < dst->m; c++) {
+        all.insert(all.end(), ks[c].begin(), ks[c].end());
+        all.insert(all.end(), kd[c].begin(), kd[c].end());
+        offs[c + 1] = all.size();
+      }
+      if ((s = cofactor_agg_align_keys(dst, all.data(), offs.data())) != COFACTOR_OK) { cleanup(); return s; }
+      if ((s = cofactor_agg_align_keys(src, all.data(), offs.data())) != COFACTOR_OK) { cleanup(); return s; }
+    }
+    // ---- tables: src image -> (src GPU) -> dst GPU -> added into dst's tables ----
+    const CatLayout &L = dst->L;
+    const size_t tlen = (size_t)L.n_cnt + L.n_s + L.n_p;
+    if (src->L.n_cnt != L.n_cnt || src->L.n_s != L.n_s || src->L.n_p != L.n_p) {
+      cleanup();
+      return fail(COFACTOR_ERR_INTERNAL, "combine: aligned states disagree on the table layout");
+    }
+    {
+      DeviceGuard g(sdev);
+      COMBINE_TRY(hipMalloc((void **)&tmp_s, std::max<size_t>(1, tlen) * sizeof(double)));
+      COMBINE_TRY(launch_cat_tables_export(src->L, src->D, tmp_s, cs->stream));
+      COMBINE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      COMBINE_TRY(hipEventRecord(ev, cs->stream));
+    }
+    {
+      DeviceGuard g(ddev);
+      COMBINE_TRY(hipStreamWaitEvent(cd->stream, ev, 0));
+      tmp_d = tmp_s;
+      if (ddev != sdev) {
+        COMBINE_TRY(hipMalloc((void **)&tmp_d, std::max<size_t>(1, tlen) * sizeof(double)));
+        COMBINE_TRY(copy_between(tmp_d, ddev, tmp_s, sdev, tlen * sizeof(double), cd->stream));
+      }
+      COMBINE_TRY(launch_cat_tables_import(dst->L, dst->D, tmp_d, /*add=*/true, cd->stream));
+      // sorted pair lists: merge src's into dst's
+      if (dst->kind == COFACTOR_TRIPLE && any_sparse_pair(L)) {
+        dst->sparse.resize(tri(dst->m));
+        for (int q = 0; q < tri(dst->m) && q < (int)src->sparse.size(); q++) {
+          const SparseStore &sp = src->sparse[q];
+          if (!pair_is_sparse(L, q) || sp.len == 0) continue;
+          const unsigned long long *k = sp.keys, *v = sp.cnt;
+          if (ddev != sdev) {
+            COMBINE_TRY(hipStreamSynchronize(cd->stream));
+            if (sp_tmp) { (void)hipFree(sp_tmp); sp_tmp = nullptr; }
+            COMBINE_TRY(hipMalloc((void **)&sp_tmp, sp.len * 16));
+            COMBINE_TRY(copy_between(sp_tmp, ddev, sp.keys, sdev, sp.len * 8, cd->stream));
+            COMBINE_TRY(copy_between(sp_tmp + sp.len, ddev, sp.cnt, sdev, sp.len * 8, cd->stream));
+            k = sp_tmp; v = sp_tmp + sp.len;
+          }
+          hipError_t e = sparse_merge_lists(cd->sparse_sc, dst->sparse[q], k, v, sp.len, cd->stream);
+          if (e == hipErrorInvalidValue) { cleanup(); return fail(COFACTOR_ERR_UNSUPPORTED, "a sparse pair table would pass 2^31 entries"); }
+          COMBINE_TRY(e);
+        }
+      }
+    }
+    dst->cat_check_pending = dst->cat_check_pending || src->cat_check_pending;
+  }
+  // ---- dense part: accumulator image and kept-row counter ----
+  if (src->dev_dirty) {
+    DeviceGuard g(ddev);
+    if (!ev) {
+      { DeviceGuard gs(sdev); COMBINE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); COMBINE_TRY(hipEventRecord(ev, cs->stream)); }
+      COMBINE_TRY(hipStreamWaitEvent(cd->stream, ev, 0));
+    }
+    const double *s_acc = src->d_acc;
+    const unsigned long long *s_kept = src->d_kept;
+    double *img = nullptr;
+    if (ddev != sdev) {                              // image + counter over to dst's GPU first
+      COMBINE_TRY(hipMalloc((void **)&img, sizeof(double) * (GRAM_ACC_LEN + 1)));
+      COMBINE_TRY(copy_between(img, ddev, src->d_acc, sdev, sizeof(double) * GRAM_ACC_LEN, cd->stream));
+      COMBINE_TRY(copy_between(img + GRAM_ACC_LEN, ddev, src->d_kept, sdev, sizeof(unsigned long long), cd->stream));
+      s_acc = img;
+      s_kept = reinterpret_cast<const unsigned long long *>(img + GRAM_ACC_LEN);
+    }
+    hipError_t e = launch_acc_add(s_acc, s_kept, dst->d_acc, dst->d_kept, cd->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(cd->stream);
+    if (img) (void)hipFree(img);
+    COMBINE_TRY(e);
+    dst->dev_rows += src->dev_rows;
+    dst->dev_dirty = true;
+  }
+  {   // src's buffers were read by dst's stream: nothing of src may change before that has passed
+    DeviceGuard g(ddev);
+    COMBINE_TRY(hipStreamSynchronize(cd->stream));
+  }
+#undef COMBINE_TRY
+  cleanup();
+  return COFACTOR_OK;
+}
+
+// ---- sorted pair lists across ranks (SURVEY.md §8e for pair tables too big to be dense) -----------------
+// A pair kept as a sorted (key1, key2) -> count list is keyed by the keys themselves: the ranks
+// gather each other's lists (variable length) and every rank merges them into its own.
+cofactor_status cofactor_agg_sparse_lens(cofactor_agg *a, uint64_t *lens, uint64_t cap) {
+  if (!a || !lens) return fail(COFACTOR_ERR_INVALID, "null argument");
+  const uint64_t np = (uint64_t)tri(a->m);
+  if (cap < np) return fail(COFACTOR_ERR_CAPACITY, "lens holds fewer than m(m+1)/2 entries");
+  CTX_LOCK(a->ctx);
+  for (uint64_t q = 0; q < np; q++)
+    lens[q] = (a->kind == COFACTOR_TRIPLE && a->cat_ready && pair_is_sparse(a->L, (int)q) && q < a->sparse.size()) ? a->sparse[q].len : 0;
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_sparse_is_list(cofactor_agg *a, int32_t pair, int32_t *is_list) {
+  if (!a || !is_list || pair < 0 || pair >= tri(a->m)) return fail(COFACTOR_ERR_INVALID, "bad argument");
+  CTX_LOCK(a->ctx);
+  *is_list = (a->kind == COFACTOR_TRIPLE && a->cat_ready && pair_is_sparse(a->L, pair)) ? 1 : 0;
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_sparse_export_device(cofactor_agg *a, int32_t pair, uint64_t *d_keys, uint64_t *d_counts) {
+  if (!a || pair < 0 || pair >= tri(a->m)) return fail(COFACTOR_ERR_INVALID, "bad argument");
+  CTX_LOCK(a->ctx);
+  DeviceGuard guard(a->ctx->device);
+  if ((size_t)pair >= a->sparse.size() || a->sparse[pair].len == 0) return COFACTOR_OK;
+  if (!d_keys || !d_counts) return fail(COFACTOR_ERR_INVALID, "null argument");
+  const SparseStore &sp = a->sparse[pair];
+  HIP_TRY(hipMemcpyAsync(d_keys, sp.keys, sp.len * 8, hipMemcpyDeviceToDevice, a->ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_counts, sp.cnt, sp.len * 8, hipMemcpyDeviceToDevice, a->ctx->stream));
+  return COFACTOR_OK;
+}
+
+cofactor_status cofactor_agg_sparse_assign_device(cofactor_agg *a, int32_t pair, const uint64_t *d_keys,
+                                                  const uint64_t *d_counts, uint64_t len) {
+  if (!a || pair < 0 || pair >= tri(a->m) || (len && (!d_keys || !d_counts))) return fail(COFACTOR_ERR_INVALID, "bad argument");
+  CTX_LOCK(a->ctx);
+  DeviceGuard guard(a->ctx->device);
+  if (!(a->kind == COFACTOR_TRIPLE && a->cat_ready && pair_is_sparse(a->L, pair)))
+    return fail(COFACTOR_ERR_INVALID, "sparse_assign: this pair table is dense in the state's layout");
+  a->sparse.resize(tri(a->m));
+  SparseStore &sp = a->sparse[pair];
+  HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+  sp.len = 0;                                       // the lists handed in REPLACE the store (they include this rank's)
+  hipError_t e = sparse_merge_lists(a->ctx->sparse_sc, sp, (const unsigned long long *)d_keys,
+                                    (const unsigned long long *)d_counts, (size_t)len, a->ctx->stream);
+  if (e == hipErrorInvalidValue) return fail(COFACTOR_ERR_UNSUPPORTED, "a sparse pair table would pass 2^31 entries");
+  if (e != hipSuccess) return hip_fail(e, "sparse_assign");
   a->dev_dirty = true;
   a->blob_cache_valid = false;
   return COFACTOR_OK;

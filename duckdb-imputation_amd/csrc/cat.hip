@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256) void cat_remap_kernel(CatLayout Lo, CatDevice 
     if (!v) continue;
     int q = 0;
     while (q + 1 < npairs && i >= Lo.p_off[q + 1]) q++;
+    if (pair_is_sparse(Ln, q)) continue;           // (moved into its sorted store by the caller)
     int c1 = 0, rem = q;
     while (rem >= Lo.m - c1) { rem -= Lo.m - c1; c1++; }
     const int c2 = c1 + rem;

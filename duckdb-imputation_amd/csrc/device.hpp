@@ -57,6 +57,10 @@ hipError_t launch_dense_export(const double *acc, const unsigned long long *kept
 hipError_t launch_dense_import(const double *in, int n, int kind, double *acc, unsigned long long *kept,
                                hipStream_t stream);
 
+// acc[GRAM_ACC_LEN] += src_acc[..], *kept += *src_kept (all on this device)
+hipError_t launch_acc_add(const double *src_acc, const unsigned long long *src_kept, double *acc,
+                          unsigned long long *kept, hipStream_t stream);
+
 // calibration kernels (cofactor_ctx_calibrate): float4 copy / read-only stream over `bytes`
 hipError_t launch_calibration(const void *src, void *dst, uint64_t bytes, int grid, bool copy, hipStream_t stream);
 uint64_t calibration_bytes(uint64_t bytes, int grid);   // bytes one launch actually reads

@@ -944,6 +944,19 @@ __global__ __launch_bounds__(GRAM_ACC_LEN) void dense_import_kernel(const double
   acc[i] = img[i];
 }
 
+// dst image += src image, dst kept-row counter += src's (SumStateCombine's dense half on the device)
+__global__ __launch_bounds__(GRAM_ACC_LEN) void acc_add_kernel(const double *__restrict__ src_acc,
+                                                               const unsigned long long *__restrict__ src_kept,
+                                                               double *__restrict__ acc, unsigned long long *__restrict__ kept) {
+  acc[threadIdx.x] += src_acc[threadIdx.x];
+  if (threadIdx.x == 0) *kept += *src_kept;
+}
+hipError_t launch_acc_add(const double *src_acc, const unsigned long long *src_kept, double *acc,
+                          unsigned long long *kept, hipStream_t stream) {
+  hipLaunchKernelGGL(acc_add_kernel, dim3(1), dim3(GRAM_ACC_LEN), 0, stream, src_acc, src_kept, acc, kept);
+  return hipGetLastError();
+}
+
 hipError_t launch_dense_export(const double *acc, const unsigned long long *kept, double n_base,
                                const double *extra, int n, int kind, double *out, hipStream_t stream) {
   hipLaunchKernelGGL(dense_export_kernel, dim3(1), dim3(256), 0, stream, acc, kept, n_base, extra, n, kind, out);

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "ring.hpp"
@@ -393,9 +394,49 @@ cofactor_status cofactor_lift_host_tvec(cofactor_ctx *ctx, const float *const *n
   return COFACTOR_OK;
 }
 
+// A host vector of triples before it goes to the device: every (offset, length) entry must stay inside
+// the extent of the array it points into — the kernels index the child arrays with these entries
+// as they are, and a NULL or malformed row that came through SQL carries uninitialised ones (an
+// out-of-bounds device read is a GPU fault, not an error code).  Row shapes are checked too.
+static cofactor_status validate_host_tvec(const cofactor_tvec &t, const char *what) {
+  auto bad = [&](const char *part) { return fail(COFACTOR_ERR_INVALID, std::string(what) + ": " + part); };
+  if (t.n < 0 || t.n > COFACTOR_MAX_NUM || t.m < 0 || t.m > COFACTOR_MAX_CAT || (t.kind != 0 && t.kind != 1))
+    return bad("bad n / m / kind");
+  if (t.count == 0) return COFACTOR_OK;
+  const uint64_t n = (uint64_t)t.n, m = (uint64_t)t.m, T = t.kind ? n : n * (n + 1) / 2;
+  if (!t.N || !t.lin_e || !t.quad_e || (n && (!t.lin || !t.quad))) return bad("null dense member");
+  auto inside = [](uint64_t off, uint64_t len, uint64_t extent) { return off <= extent && len <= extent - off; };
+  for (uint64_t i = 0; i < t.count; i++) {
+    if (t.lin_e[2 * i + 1] != n || !inside(t.lin_e[2 * i], n, t.lin_len)) return bad("a lin entry leaves the lin array (or is not n long)");
+    if (t.quad_e[2 * i + 1] != T || !inside(t.quad_e[2 * i], T, t.quad_len)) return bad("a quad entry leaves the quad array (or has the wrong length)");
+  }
+  auto lists = [&](const uint64_t *outer, const uint64_t *sub, uint64_t subs, uint64_t cap, uint64_t per_row,
+                   const void *k1, const void *k2, const void *val, bool two, const char *name) -> cofactor_status {
+    if (per_row == 0) return COFACTOR_OK;
+    if (!outer || !sub) return bad("null list member");
+    for (uint64_t i = 0; i < t.count; i++) {
+      const uint64_t off = outer[2 * i], len = outer[2 * i + 1];
+      if (len != per_row || !inside(off, len, subs)) return fail(COFACTOR_ERR_INVALID, std::string(what) + ": an outer " + name + " entry leaves its sub-list array (or has the wrong length)");
+      for (uint64_t j = off; j < off + len; j++)
+        if (!inside(sub[2 * j], sub[2 * j + 1], cap)) return fail(COFACTOR_ERR_INVALID, std::string(what) + ": a " + name + " sub-list leaves its payload arrays");
+    }
+    if (cap && (!k1 || !val || (two && !k2))) return bad("null payload member");
+    return COFACTOR_OK;
+  };
+  cofactor_status s = lists(t.lc_outer, t.lc_sub, t.lc_subs, t.lc_cap, m, t.lc_key, nullptr, t.lc_val, false, "lin_cat");
+  if (s != COFACTOR_OK || t.kind) return s;
+  s = lists(t.nc_outer, t.nc_sub, t.nc_subs, t.nc_cap, n * m, t.nc_key, nullptr, t.nc_val, false, "quad_num_cat");
+  if (s != COFACTOR_OK) return s;
+  return lists(t.cc_outer, t.cc_sub, t.cc_subs, t.cc_cap, m * (m + 1) / 2, t.cc_key1, t.cc_key2, t.cc_val, true, "quad_cat");
+}
+
 cofactor_status cofactor_agg_update_tvec_host(cofactor_agg *a, const cofactor_tvec *v) {
   if (!a || !v) return fail(COFACTOR_ERR_INVALID, "null argument");
   if (v->count == 0) return COFACTOR_OK;
+  {
+    cofactor_status vs = validate_host_tvec(*v, "update_tvec_host");
+    if (vs != COFACTOR_OK) return vs;
+  }
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   DevTvec dv;
@@ -412,6 +453,14 @@ cofactor_status cofactor_multiply_host(cofactor_ctx *ctx, const cofactor_tvec *a
                                        const cofactor_tvec *b, const uint32_t *b_sel, uint64_t rows, cofactor_tvec *out,
                                        uint64_t *lc_need, uint64_t *nc_need, uint64_t *cc_need) {
   if (!ctx || !a || !b) return fail(COFACTOR_ERR_INVALID, "null argument");
+  {
+    cofactor_status vs = validate_host_tvec(*a, "multiply_host (left)");
+    if (vs == COFACTOR_OK) vs = validate_host_tvec(*b, "multiply_host (right)");
+    if (vs != COFACTOR_OK) return vs;
+    for (uint64_t i = 0; i < rows; i++)
+      if ((a_sel ? a_sel[i] : i) >= a->count || (b_sel ? b_sel[i] : i) >= b->count)
+        return fail(COFACTOR_ERR_INVALID, "multiply_host: a selection entry points past its vector");
+  }
   CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   hipStream_t st = ctx->stream;

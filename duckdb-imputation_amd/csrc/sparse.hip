@@ -236,6 +236,18 @@ hipError_t sparse_add_dense(SparseScratch &sc, SparseStore &st, const unsigned l
   return merge_into(sc, st, keys, vals, (size_t)c, false, stream);
 }
 
+hipError_t sparse_merge_lists(SparseScratch &sc, SparseStore &st, const unsigned long long *keys,
+                              const unsigned long long *cnt, size_t len, hipStream_t stream) {
+  if (len == 0) return hipSuccess;
+  hipError_t e;
+  if ((e = ensure_counter(sc)) != hipSuccess) return e;
+  if ((e = reserve(sc, 0, len * 8, stream)) != hipSuccess) return e;
+  if ((e = reserve(sc, 1, len * 8, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(sc.buf[0], keys, len * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(sc.buf[1], cnt, len * 8, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+  return merge_into(sc, st, (unsigned long long *)sc.buf[0], (unsigned long long *)sc.buf[1], len, /*sorted_unique=*/false, stream);
+}
+
 hipError_t launch_key_of_code(const unsigned long long *slots, const int32_t *codes, int cap, int kc, int32_t *key_of,
                               hipStream_t stream) {
   hipLaunchKernelGGL(key_of_code_kernel, dim3(grid_for((uint64_t)cap)), dim3(256), 0, stream, slots, codes, cap, kc, key_of);

@@ -49,6 +49,11 @@ hipError_t sparse_add_rows(SparseScratch &sc, SparseStore &st, const int32_t *co
 hipError_t sparse_add_dense(SparseScratch &sc, SparseStore &st, const unsigned long long *table, int kc1, int kc2,
                             const int32_t *key_of1, const int32_t *key_of2, hipStream_t stream);
 
+// st += (keys[i], cnt[i]), i < len (device arrays of this device, any order, duplicates allowed; the
+// arrays are only read): another state's store (combine), or the gathered stores of all ranks.
+hipError_t sparse_merge_lists(SparseScratch &sc, SparseStore &st, const unsigned long long *keys,
+                              const unsigned long long *cnt, size_t len, hipStream_t stream);
+
 // key_of[code] = key for one column's dictionary (slots / codes of that column, cap slots)
 hipError_t launch_key_of_code(const unsigned long long *slots, const int32_t *codes, int cap, int kc, int32_t *key_of,
                               hipStream_t stream);

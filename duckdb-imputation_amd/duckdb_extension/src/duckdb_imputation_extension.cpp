@@ -40,17 +40,54 @@
 namespace duckdb {
 namespace cofactor_glue {
 
-// ---- one GPU context per process ----------------------------------------------------------------
-static cofactor_ctx *Context() {
+// ---- one GPU context per visible GPU ---------------------------------------------------------------
+// DuckDB runs the aggregate on thread-local states and merges them with combine
+// (reference: duckdb_extension/src/triple/sum/sum_state.cpp:10-114, registered at
+// duckdb_imputation_extension.cpp:97-106): that seam is the multi-GPU seam of the extension.  Every
+// worker thread sticks to one context (round-robin over the GPUs), the states it creates live on
+// that GPU, its chunks are staged to that GPU, and cofactor_agg_combine merges states of different
+// GPUs on the device (peer copy of the aligned table image over xGMI + an add kernel).
+//   COFACTOR_DEVICES="0,1,2,3"   the GPUs to use (a device may be listed twice: two contexts on it)
+//   COFACTOR_DEVICE=k            one GPU (round 1/2 behaviour)
+//   neither                      all GPUs HIP shows
+static std::vector<cofactor_ctx *> &Contexts() {
   static std::once_flag once;
-  static cofactor_ctx *ctx = nullptr;
+  static std::vector<cofactor_ctx *> ctxs;
   std::call_once(once, [] {
-    const char *dev = std::getenv("COFACTOR_DEVICE");
-    if (cofactor_ctx_create(dev ? std::atoi(dev) : 0, &ctx) != COFACTOR_OK)
-      throw IOException("duckdb_imputation (MI355X): %s", cofactor_last_error());
+    std::vector<int> devs;
+    if (const char *list = std::getenv("COFACTOR_DEVICES")) {
+      for (const char *p = list; *p;) {
+        char *end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end == p) break;
+        devs.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+      }
+    } else if (const char *dev = std::getenv("COFACTOR_DEVICE")) {
+      devs.push_back(std::atoi(dev));
+    } else {
+      const int n = cofactor_device_count();
+      for (int d = 0; d < n; d++) devs.push_back(d);
+    }
+    if (devs.empty()) devs.push_back(0);             // (no GPU: the create below reports it)
+    for (int d : devs) {
+      cofactor_ctx *ctx = nullptr;
+      if (cofactor_ctx_create(d, &ctx) != COFACTOR_OK)
+        throw IOException("duckdb_imputation (MI355X): %s", cofactor_last_error());
+      ctxs.push_back(ctx);
+    }
   });
-  return ctx;
+  return ctxs;
 }
+// the calling worker thread's context
+static cofactor_ctx *Context() {
+  static std::atomic<unsigned> next{0};
+  auto &ctxs = Contexts();
+  thread_local unsigned mine = next.fetch_add(1);
+  return ctxs[mine % ctxs.size()];
+}
+// the GROUP BY pool of a query lives on ONE GPU (its table rows are updated by one kernel per chunk)
+static cofactor_ctx *PoolContext() { return Contexts()[0]; }
 
 static void Check(cofactor_status st) {
   if (st != COFACTOR_OK) throw InvalidInputException("duckdb_imputation (MI355X): %s", cofactor_last_error());
@@ -78,6 +115,19 @@ struct RingState {
 struct RingBindData : public VariableReturnBindData {
   explicit RingBindData(LogicalType t) : VariableReturnBindData(std::move(t)), pool(std::make_shared<GroupPool>()) {}
   std::shared_ptr<GroupPool> pool;
+  // DuckDB copies bound aggregates (optimizer rewrites, CTE / view inlining, DISTINCT): the base
+  // class's Copy() would hand back a plain VariableReturnBindData and the Cast<RingBindData>() in
+  // RingUpdate would read a pool that is not there.  A copy SHARES the pool (it belongs to the same
+  // query; states carry their pool pointer, RingCombine checks it).
+  unique_ptr<FunctionData> Copy() const override {
+    auto copy = make_uniq<RingBindData>(stype);
+    copy->pool = pool;
+    return std::move(copy);
+  }
+  bool Equals(const FunctionData &other_p) const override {
+    auto &other = other_p.Cast<RingBindData>();
+    return stype == other.stype && pool == other.pool;
+  }
 };
 
 struct RingStateFunction {
@@ -277,7 +327,7 @@ static void RingUpdate(Vector inputs[], AggregateInputData &aggr, idx_t cols, Ve
   vector<uint32_t> pooled;
   {
     std::lock_guard<std::mutex> lock(pool->mu);
-    if (!pool->grp) Check(cofactor_groups_create(Context(), (int)num.size(), (int)cat.size(), kind, /*is_key=*/0, &pool->grp));
+    if (!pool->grp) Check(cofactor_groups_create(PoolContext(), (int)num.size(), (int)cat.size(), kind, /*is_key=*/0, &pool->grp));
     for (idx_t i = 0; i < count; i++) {
       RingState *st = states[sdata.sel->get_index(i)];
       if (st->agg && st->slot < 0) { rows_of[st].push_back((uint32_t)i); continue; }

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define COFACTOR_ABI_VERSION 2
+#define COFACTOR_ABI_VERSION 3
 /* sum_to_triple_<x>_<y> is registered for x,y in 0..20 (the reference registers 0..19,
  * duckdb_imputation_extension.cpp:80-84; README.md:136 documents "up to 20"). */
 #define COFACTOR_MAX_NUM 20
@@ -66,6 +66,10 @@ typedef struct cofactor_agg cofactor_agg; /* one aggregate state (what a Triple:
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *cofactor_last_error(void);
 int cofactor_abi_version(void);
+
+/* Number of GPUs HIP shows to this process (0 when there is none): what a host that opens one
+ * context per GPU iterates over. */
+int cofactor_device_count(void);
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* Opens HIP device `device`.  Fails with COFACTOR_ERR_NO_DEVICE when there is no GPU: there is
@@ -109,9 +113,10 @@ cofactor_status cofactor_agg_reset(cofactor_agg *agg);
  * are dense in the key's code).  A pair table (sum_no_lift.cpp:195-214) is dense, code-indexed,
  * while it has at most 2^26 cells and all dense pair tables together at most 2^30; beyond that the
  * pair is kept as a sorted (key1, key2) -> count list in device memory, like the reference's
- * std::map.  States that hold such lists work with update / combine / finalize / reset; the
- * dictionary-aligned table exchange, sum_triple into them and the GROUP BY pool return
- * COFACTOR_ERR_UNSUPPORTED.
+ * std::map.  States that hold such lists work with update / combine / finalize / reset and with the
+ * multi-GPU seam (the dense tables are aligned and all-reduced as usual, the lists are gathered and
+ * merged: cofactor_agg_sparse_*, cofactor_agg_allreduce); sum_triple into them and the GROUP BY
+ * pool return COFACTOR_ERR_UNSUPPORTED.
  *
  * Device form: the columns are resident in this context's HBM (d_num[k] -> float[rows],
  * d_cat[c] -> int32[rows]; the pointer arrays themselves are host arrays).  Asynchronous on the
@@ -150,7 +155,13 @@ cofactor_status cofactor_agg_update_triples(cofactor_agg *agg, const double *blo
                                             const uint64_t *offsets, uint64_t count);
 
 /* combine — Triple::SumStateCombine (duckdb_extension/src/triple/sum/sum_state.cpp:10-114):
- * dst += src.  src is left unchanged.  Handles may live on different contexts (GPUs). */
+ * dst += src, on the device: the accumulator image is added by a kernel (sum_state.cpp:25,73-83); the
+ * two states' dictionaries are aligned to the union of their key lists (only the key lists, a few
+ * KB, pass through the host, and nothing at all while both states still hold a common alignment),
+ * then src's table image [cnt | s | p] is added into dst's (sum_state.cpp:87-111 as a dense sum) and
+ * sorted pair lists are merged.  src keeps its value (its tables may be re-indexed).  The handles may
+ * live on different contexts, also on different GPUs: the image then travels by a peer copy (xGMI)
+ * — this is how a DuckDB process with one context per GPU merges its thread-local states. */
 cofactor_status cofactor_agg_combine(cofactor_agg *dst, cofactor_agg *src);
 
 /* finalize — Triple::SumStateFinalize (sum_state.cpp:116-464): writes the flat triple blob.
@@ -201,6 +212,38 @@ cofactor_status cofactor_agg_align_keys(cofactor_agg *agg, const int32_t *keys,
 uint64_t cofactor_agg_tables_len(cofactor_agg *agg);
 cofactor_status cofactor_agg_export_tables_device(cofactor_agg *agg, double *d_out);
 cofactor_status cofactor_agg_import_tables_device(cofactor_agg *agg, const double *d_in);
+
+/* Pair tables kept as sorted lists (see update) across ranks: list q (upper-triangle index, c1 outer,
+ * c2 >= c1) is `lens[q]` entries of (packed key pair, count), packed = (key1 ^ 2^31) << 32 | (key2 ^
+ * 2^31), ascending.  The ranks gather each other's lists and every rank hands the concatenation of
+ * ALL ranks' lists (its own included, any order, duplicates allowed) to sparse_assign, which sorts,
+ * adds up equal keys and makes the result the state's list.  is_list tells whether pair q is a list
+ * under the state's current (aligned) layout — the same answer on every rank after align_keys. */
+cofactor_status cofactor_agg_sparse_lens(cofactor_agg *agg, uint64_t *lens, uint64_t cap);
+cofactor_status cofactor_agg_sparse_is_list(cofactor_agg *agg, int32_t pair, int32_t *is_list);
+cofactor_status cofactor_agg_sparse_export_device(cofactor_agg *agg, int32_t pair, uint64_t *d_keys,
+                                                  uint64_t *d_counts);
+cofactor_status cofactor_agg_sparse_assign_device(cofactor_agg *agg, int32_t pair, const uint64_t *d_keys,
+                                                  const uint64_t *d_counts, uint64_t len);
+
+/* The whole seam below the C ABI: a communicator of the library itself (RCCL, loaded with dlopen when
+ * the first communicator is made; no torch, no MPI) and ONE call that turns every rank's state into
+ * the merge of all ranks' states — Triple::SumStateCombine across GPUs (sum_state.cpp:10-114):
+ *   a small all-gather of (status, dictionary signature, key counts); only when some rank's
+ *   dictionaries changed since the last common alignment, an all-gather of the key lists and
+ *   cofactor_agg_align_keys; ONE ncclAllReduce(sum, double) of [N, lin, quad | cnt | s | p] on the
+ *   context stream between the export and import kernels; sorted pair lists gathered and merged.
+ * Every rank returns the same status: a rank that fails before the all-reduce says so in the first
+ * exchange and all ranks return COFACTOR_ERR_INVALID together instead of hanging in the collective.
+ * One process per GPU: rank 0 makes the 128-byte id, the caller ships it to the other ranks (the
+ * launcher's rendezvous, a file, a socket), every rank calls comm_create with the same id. */
+typedef struct cofactor_comm cofactor_comm;
+#define COFACTOR_COMM_ID_BYTES 128
+cofactor_status cofactor_comm_unique_id(void *id_out);
+cofactor_status cofactor_comm_create(cofactor_ctx *ctx, const void *id, int rank, int world,
+                                     cofactor_comm **out);
+void cofactor_comm_destroy(cofactor_comm *comm);
+cofactor_status cofactor_agg_allreduce(cofactor_agg *agg, cofactor_comm *comm);
 
 /* ---- scalar ring ops on flat triple blobs (host; tiny per-row work) ---------------------------
  * All use the two-call protocol of cofactor_agg_finalize. */

@@ -227,12 +227,19 @@ struct ExpressionState {};
 struct Expression {};
 struct FunctionData {
   virtual ~FunctionData() {}
+  virtual unique_ptr<FunctionData> Copy() const = 0;
+  virtual bool Equals(const FunctionData &other) const = 0;
+  // DuckDB's Cast is an unchecked reinterpret in release builds; the stand-in checks, so a glue that
+  // casts a plain VariableReturnBindData to its own subclass fails the test instead of reading garbage
   template <class TARGET> TARGET &Cast() { return dynamic_cast<TARGET &>(*this); }
+  template <class TARGET> const TARGET &Cast() const { return dynamic_cast<const TARGET &>(*this); }
 };
 struct AggregateInputData { FunctionData *bind_data = nullptr; };   // (optional_ptr<FunctionData> in DuckDB)
 struct VariableReturnBindData : FunctionData {
   LogicalType stype;
   explicit VariableReturnBindData(LogicalType t) : stype(std::move(t)) {}
+  unique_ptr<FunctionData> Copy() const override { return make_uniq<VariableReturnBindData>(stype); }   // (as DuckDB 0.9.2's)
+  bool Equals(const FunctionData &other_p) const override { return stype == other_p.Cast<VariableReturnBindData>().stype; }
   static void Serialize() {}
   static void Deserialize() {}
 };

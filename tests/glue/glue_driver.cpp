@@ -8,6 +8,7 @@
 #include <map>
 #include <iomanip>
 #include <sstream>
+#include <thread>
 #include <string>
 
 #include "duckdb.hpp"
@@ -196,6 +197,40 @@ int main() {
         t2.CombineInto(global);
         Vector r = global.Finalize();
         out << ",\"" << pfx << "sum_combined\":" << Rows(r, 2);
+      }
+      {  // the same through a COPY of the bind data (DuckDB copies bound aggregates: optimizer rewrites,
+         // CTE inlining) with per-row state pointers, i.e. through the GROUP BY pool the copy must share
+        AggRun global(fn33, 2);
+        std::shared_ptr<FunctionData> copy(global.bind_data->Copy().release());
+        if (!copy->Equals(*global.bind_data)) throw std::runtime_error("a copy of the bind data must equal it");
+        AggRun t1(fn33, 2, copy), t2(fn33, 2, global.bind_data);
+        auto c1 = Cols("abcdef", {0, 2, 3}, true);
+        t1.Update(c1, {0, 1, 1});
+        auto c2 = Cols("abcdef", {1, 4}, true);
+        t2.Update(c2, {0, 1});
+        t1.CombineInto(global);
+        t2.CombineInto(global);
+        Vector r = global.Finalize();
+        out << ",\"" << pfx << "sum_combined_copied_bind\":" << Rows(r, 2);
+      }
+      {  // two WORKER THREADS: each sticks to its own context (COFACTOR_DEVICES lists two), their
+         // thread-local states are merged by combine across the contexts — the extension's multi-GPU seam
+        AggRun global(fn33, 1);
+        AggRun t1(fn33, 1, global.bind_data), t2(fn33, 1, global.bind_data);
+        std::exception_ptr err;
+        auto work = [&](AggRun *run, std::vector<int> rows) {
+          try {
+            auto c = Cols("abcdef", rows, false);
+            run->Update(c, std::vector<int>(rows.size(), 0));
+          } catch (...) { err = std::current_exception(); }
+        };
+        std::thread a(work, &t1, std::vector<int>{0, 2, 3}), b(work, &t2, std::vector<int>{1, 4});
+        a.join(); b.join();
+        if (err) std::rethrow_exception(err);
+        t1.CombineInto(global);
+        t2.CombineInto(global);
+        Vector r = global.Finalize();
+        out << ",\"" << pfx << "sum_two_contexts\":" << Rows(r, 1);
       }
       {  // SELECT to_cofactor(a,b,c,d,e,f) FROM test, then sum_triple(...) GROUP BY gb
         auto &lift = db.scalars.at(nb ? "to_nb_agg" : "to_cofactor");

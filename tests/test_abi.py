@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(cofactor_hip.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.cofactor_abi_version() == 2
+    assert lib.cofactor_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

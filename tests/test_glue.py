@@ -28,7 +28,9 @@ def test_glue_compiles_against_the_api_stand_in():
 def test_glue_callbacks_reproduce_reference_goldens(goldens, ref_table):
     ref_tables = ref_table
     subprocess.check_call(["make", "-s", "-C", GLUE, "glue_driver"])
-    out = subprocess.run([os.path.join(GLUE, "glue_driver")], capture_output=True, text=True, timeout=300)
+    # two contexts (on a one-GPU box both on device 0): worker threads are spread over them
+    env = dict(os.environ, COFACTOR_DEVICES="0,0")
+    out = subprocess.run([os.path.join(GLUE, "glue_driver")], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr
     doc = json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -44,6 +46,8 @@ def test_glue_callbacks_reproduce_reference_goldens(goldens, ref_table):
         grouped = _expected(goldens, fname, 1)
         assert doc[pfx + "sum_group_by"] == grouped          # dictionary vectors, two chunks
         assert doc[pfx + "sum_combined"] == grouped          # thread-local states combined
+        assert doc[pfx + "sum_combined_copied_bind"] == grouped   # ... through a Copy() of the bind data (shared pool)
+        assert doc[pfx + "sum_two_contexts"] == _expected(goldens, fname, 0)   # two threads, two contexts, combine
         # sum_triple(to_cofactor(..)) == sum_to_triple(..): same values, aggregate field names
         assert doc[pfx + "sum_lifted_group_by"] == grouped
         # the ungrouped sum_triple over the same lifted chunk, fed twice: every value doubles

@@ -279,3 +279,43 @@ def test_factorised_join_with_100k_groups(ctx):
         for k2 in range(4):
             want = float((per_group(t1, t1["d"] == k1) * per_group(t2, t2["f"] == k2)).sum())
             assert pairs[(k1, k2)] == want
+
+
+def test_host_vectors_with_entries_outside_their_extents_are_refused(ctx):
+    """The *_host entry points copy the child arrays by their declared extents and the kernels index
+    them with the (offset, length) entries as they are: an entry that leaves its extent (a NULL or
+    malformed row that came through SQL carries uninitialised list entries) must come back as
+    COFACTOR_ERR_INVALID before anything is launched, not as an out-of-bounds device read."""
+    rng = np.random.default_rng(5)
+    num = [rng.normal(size=50).astype(np.float32) for _ in range(2)]
+    cat = [rng.integers(0, 5, 50).astype(np.int32) for _ in range(2)]
+    good = ring.lift_host_tvec(ctx, num, cat, cofactor_hip.TRIPLE)
+    agg = ctx.aggregate(2, 2)
+    ring.update_tvec(agg, good)                       # a well-formed vector goes through
+
+    def refused(mutate, restore):
+        mutate()
+        try:
+            with pytest.raises(cofactor_hip.CofactorError) as e:
+                ring.update_tvec(agg, good)
+            assert e.value.status == cofactor_hip.ERR_INVALID
+            with pytest.raises(cofactor_hip.CofactorError) as e:
+                ring.multiply(ctx, good, good)
+            assert e.value.status == cofactor_hip.ERR_INVALID
+        finally:
+            restore()
+
+    s = good.struct
+    # truncated extents: the last rows' entries now point past them
+    for field in ("lin_len", "quad_len", "lc_subs", "nc_subs", "cc_subs", "lc_cap", "nc_cap", "cc_cap"):
+        old = getattr(s, field)
+        refused(lambda: setattr(s, field, old - 1), lambda: setattr(s, field, old))
+    # a wild offset in one sub-list entry / one outer entry / one dense entry
+    for name, idx in (("cc_sub", 2 * 7), ("nc_outer", 2 * 3), ("lin_e", 2 * 11), ("lc_sub", 2 * 5 + 1)):
+        arr = good.a[name]
+        old = int(arr[idx])
+        refused(lambda: arr.__setitem__(idx, 1 << 40), lambda: arr.__setitem__(idx, old))
+    ring.update_tvec(agg, good)                       # untouched again: accepted
+    want = orc.State(orc.WIDE).update(num, cat).update(num, cat)
+    assert blob_to_dict(agg.finalize()) == blob_to_dict(want.finalize())
+    agg.close()

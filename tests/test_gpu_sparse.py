@@ -88,15 +88,22 @@ def test_combine_and_host_chunks_with_sparse_pairs(ctx):
     assert got == want_of(num, cat)
 
 
-def test_table_seam_refuses_sparse_states(ctx):
+def test_table_seam_takes_states_with_sorted_pair_lists(ctx):
+    """align_keys / the table image work on a state whose big pair table is a sorted list: the dense
+    tables are re-indexed, the list is keyed by the keys themselves and stays as it is; the value of
+    the state does not change.  (Across ranks the lists are gathered and merged:
+    tests/test_gpu_dist.py::test_two_ranks_with_pair_tables_kept_as_sorted_lists.)"""
     rng = np.random.default_rng(3)
     num, cat = table(rng, 10_000, 1, (200, 180))
     agg = ctx.aggregate(1, 2)
     agg.update_device(to_gpu(num), to_gpu(cat))
+    want = want_of(num, cat)
+    assert blob_to_dict(agg.finalize()) == want
     keys, offs = agg.keys()
-    with pytest.raises(cofactor_hip.CofactorError) as e:
-        agg.align_keys(keys, offs)
-    assert e.value.status == cofactor_hip.ERR_UNSUPPORTED
+    agg.align_keys(keys, offs)
+    assert agg.dict_signature() != 0
+    assert any(agg.sparse_is_list(q) for q in range(3)) and int(agg.sparse_lens().sum()) > 0
+    assert blob_to_dict(agg.finalize()) == want
     agg.close()
 
 
