@@ -600,8 +600,15 @@ def test_table_seam_alignment_and_roundtrip(ctx, n, m, nb, keys):
         return keep[-1]
     agg.update_device(d(num, 0, 15_000), d(cat, 0, 15_000))
     other.update_device(d(num, 15_000, rows), d(cat, 15_000, rows))
-    agg.combine(other)
+    agg.combine(other)                            # on the device: both states aligned to the union of their keys
     other.close()
+    assert agg.dict_signature() != 0
+    # a few lifted rows on top (sum_triple's blob form): they sit on the HOST side of the state
+    extra_num = [c[:7].copy() for c in num]
+    extra_cat = [c[:7].copy() for c in cat]
+    agg.update_triples(cofactor_hip.lift_host(extra_num, extra_cat, kind))
+    num = [np.concatenate([c, e]) for c, e in zip(num, extra_num)]
+    cat = [np.concatenate([c, e]) for c, e in zip(cat, extra_cat)]
     want = blob_to_dict(orc.State(orc.WIDE).update(num, cat, nb=nb).finalize())
     assert agg.dict_signature() == 0
     own, offs = agg.keys()

@@ -289,7 +289,7 @@ def test_host_vectors_with_entries_outside_their_extents_are_refused(ctx):
     rng = np.random.default_rng(5)
     num = [rng.normal(size=50).astype(np.float32) for _ in range(2)]
     cat = [rng.integers(0, 5, 50).astype(np.int32) for _ in range(2)]
-    good = ring.lift_host_tvec(ctx, num, cat, cofactor_hip.TRIPLE)
+    good = ring.lift_host(ctx, num, cat, cofactor_hip.TRIPLE)
     agg = ctx.aggregate(2, 2)
     ring.update_tvec(agg, good)                       # a well-formed vector goes through
 
