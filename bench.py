@@ -94,20 +94,24 @@ def cpu_baseline(num, cat, rows_mt, rows_1t, n, m, nb):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, cores)
+    # per_row_pointers: every 2048-row chunk through a vector of state pointers read per row, as the
+    # executor drives the reference's update (sum_no_lift.cpp:84,94,139) — SURVEY.md §8(d)'s baseline
     t0 = time.perf_counter()
-    orc.State(orc.FAITHFUL).update([c[:rows_1t] for c in h_num], [c[:rows_1t] for c in h_cat], nb=nb)
+    orc.State(orc.FAITHFUL).update([c[:rows_1t] for c in h_num], [c[:rows_1t] for c in h_cat], nb=nb,
+                                   threads=1, per_row_pointers=True)
     dt1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    orc.State(orc.FAITHFUL).update(h_num, h_cat, nb=nb, threads=cores)
+    orc.State(orc.FAITHFUL).update(h_num, h_cat, nb=nb, threads=cores, per_row_pointers=True)
     dtm = time.perf_counter() - t0
     name = "sum_to_%s_%d_%d" % ("nb_agg" if nb else "triple", n, m)
     return {"value": rows_mt / dtm, "unit": "rows/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(),
             "one_thread": {"value": rows_1t / dt1, "unit": "rows/s", "cores": 1,
                            "sample": "first %d rows, %.2f s wall" % (rows_1t, dt1)},
+            "path": "per-row state pointers (one 2048-entry pointer vector per chunk, read per row)",
             "sample": "first %d rows of the bench table, %s, oracle (CPU restatement of the reference's "
-                      "update loop) in faithful-fp32 mode, %d threads (thread-local states + combine), "
-                      "%.2f s wall" % (rows_mt, name, cores, dtm)}
+                      "update loop) in faithful-fp32 mode, per-row state pointers, %d threads (thread-local "
+                      "states + combine), %.2f s wall" % (rows_mt, name, cores, dtm)}
 
 
 def calibrate(ctx):
@@ -280,7 +284,7 @@ def main():
         bytes_per_row = 4 * (n + m)
         cands = [("gram_kernel", prof["gram_ms"], prof["gram_launches"], 4 * n * rows),
                  ("cat_accumulate_kernel", prof["cat_ms"], prof["cat_launches"], bytes_per_row * rows),
-                 ("fused_kernel", prof["fused_ms"], prof["fused_launches"], bytes_per_row * rows)]
+                 (prof.get("fused_kernel", "fused_kernel"), prof["fused_ms"], prof["fused_launches"], bytes_per_row * rows)]
         kname, kms, kl, kbytes = max(cands, key=lambda c: c[1])       # the dominant kernel
         avg_ms = kms / max(1, kl)
         achieved = kbytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

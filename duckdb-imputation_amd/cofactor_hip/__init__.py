@@ -19,7 +19,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_INTE
 SYMBOLS = [
     "cofactor_last_error", "cofactor_abi_version", "cofactor_device_count",
     "cofactor_ctx_create", "cofactor_ctx_destroy", "cofactor_ctx_synchronize", "cofactor_ctx_stream",
-    "cofactor_ctx_profile_enable", "cofactor_ctx_profile_read", "cofactor_ctx_calibrate",
+    "cofactor_ctx_profile_enable", "cofactor_ctx_profile_kernel", "cofactor_ctx_profile_read", "cofactor_ctx_calibrate",
     "cofactor_agg_create", "cofactor_agg_destroy", "cofactor_agg_reset",
     "cofactor_agg_update_device", "cofactor_agg_update_device_masked", "cofactor_agg_update_host",
     "cofactor_agg_update_triples",
@@ -74,6 +74,8 @@ def lib():
         L.cofactor_ctx_stream.argtypes = [vp]
         L.cofactor_ctx_stream.restype = vp
         L.cofactor_ctx_profile_enable.argtypes = [vp, C.c_int]
+        L.cofactor_ctx_profile_kernel.argtypes = [vp]
+        L.cofactor_ctx_profile_kernel.restype = C.c_char_p
         L.cofactor_ctx_profile_read.argtypes = [vp] + [C.POINTER(C.c_double), pu64] * 3
         L.cofactor_ctx_calibrate.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.cofactor_agg_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, pp]
@@ -180,6 +182,7 @@ class Context:
         out = {}
         for name, a, b in zip(("gram", "cat", "fused"), ms, ln):
             out[name + "_ms"], out[name + "_launches"] = a.value, b.value
+        out["fused_kernel"] = (lib().cofactor_ctx_profile_kernel(self._h) or b"").decode() or "fused_kernel"
         return out
 
     def calibrate(self, nbytes=4 << 30, reps=5):

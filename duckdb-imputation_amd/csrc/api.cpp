@@ -380,7 +380,7 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
   for (int c = 0; c < L.m; c++) sums_fit = sums_fit && cat_sums_lds_bytes(L, 1u << c, do_s) <= ctx->lds_budget;
   // what the one-hot MFMA kernel can take: triple kind, every column <= 16 keys
   const int groups_n = (L.n + 9) / 10, groups_m = (L.m + 9) / 10;
-  bool small_keys = L.kind == 0 && ctx->allow_fused && rows >= 16 * FUSED_TILE_ROWS && env_long("COFACTOR_NO_SUB", 0) == 0;
+  bool small_keys = L.kind == 0 && ctx->allow_fused && rows >= 16 * FUSED_TILE_ROWS && !ctx->no_sub;
   for (int c = 0; c < L.m; c++) small_keys = small_keys && a->nkeys_host[c] <= 16 && L.kc[c] == 16;
   const bool mfma_sums = small_keys && do_s && sums_fit &&
                          fused2_sub_fits((L.n + groups_n - 1) / groups_n, (L.m + groups_m - 1) / groups_m, mask != nullptr, L,
@@ -703,6 +703,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       skip = ctx->skip;
       HIP_TRY(hipMemsetAsync(skip, 0, sizeof(unsigned), st));
     }
+    ctx->last_fused = v3 ? "fused3_kernel" : (v1 ? "fused_kernel" : "fused2_kernel");
     if (v3)
       HIP_TRY(launch_fused3(num, cat, main_rows, a->L, a->D, grid, ctx->lds_max, ctx->partials, ctx->pair_slabs,
                             skip, a->d_acc, st, e0, e1, mask, a->d_kept));
@@ -878,7 +879,7 @@ static cofactor_status stage_enqueue(cofactor_agg *a) {
   CatCols cat{};
   // a buffer is [column][cap]: when it is (nearly) full the columns go up in ONE copy (20 copies
   // of 1 MB reach about half of what the link gives a single 20 MB copy)
-  const bool whole = rows * 8 >= cap * 7 && env_long("COFACTOR_STAGE_SPLIT", 0) == 0;
+  const bool whole = rows * 8 >= cap * 7 && !a->ctx->stage_split;
   if (whole) {
     if (a->n) {
       const uint64_t off = (uint64_t)b * a->n * cap;
@@ -1234,6 +1235,9 @@ cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   ctx->allow_fused = env_long("COFACTOR_NO_FUSED", 0) == 0;
   ctx->allow_optimistic = env_long("COFACTOR_NO_OPTIMISTIC", 0) == 0;
   ctx->fused_pref = (int)env_long("COFACTOR_FUSED", 0);
+  ctx->no_sub = env_long("COFACTOR_NO_SUB", 0) != 0;
+  ctx->stage_split = env_long("COFACTOR_STAGE_SPLIT", 0) != 0;
+  ctx->stage_rows_max = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
   HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)ctx->gram_grid * GRAM_ACC_LEN));
   *out = ctx.release();
   return COFACTOR_OK;
@@ -1277,6 +1281,8 @@ cofactor_status cofactor_ctx_profile_enable(cofactor_ctx *ctx, int on) {
   ctx->profiling = on != 0;
   return COFACTOR_OK;
 }
+
+const char *cofactor_ctx_profile_kernel(cofactor_ctx *ctx) { return ctx ? ctx->last_fused : ""; }
 
 cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms, uint64_t *gram_launches,
                                           double *cat_ms, uint64_t *cat_launches, double *fused_ms,
@@ -1458,7 +1464,7 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
   // Staging starts small and grows with the rows a state actually receives (x8 per full buffer up
   // to COFACTOR_STAGE_ROWS): a GROUP BY with thousands of states must not pin 2 x 20 MB for each.
   if (!a->stage_cap) {
-    const uint64_t max_rows = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
+    const uint64_t max_rows = a->ctx->stage_rows_max;
     cofactor_status s = stage_alloc(a, std::min<uint64_t>(max_rows, 512));
     if (s != COFACTOR_OK) return s;
   }
@@ -1492,7 +1498,7 @@ cofactor_status cofactor_agg_update_host(cofactor_agg *a, const float *const *nu
     if (a->stage_rows == a->stage_cap) {
       cofactor_status s = stage_flush(a);
       if (s != COFACTOR_OK) return s;
-      const uint64_t max_rows = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
+      const uint64_t max_rows = a->ctx->stage_rows_max;
       if (a->stage_cap < max_rows) {
         s = stage_alloc(a, std::min(max_rows, a->stage_cap * 8));
         if (s != COFACTOR_OK) return s;

@@ -552,8 +552,7 @@ F2Carve f2_carve(const CatLayout &L, const F2Shape &sh, bool masked, int ring) {
 // per CU — one wave per SIMD hides no latency at all.  COFACTOR_F2_WGS overrides (experiments).
 int f2_wgs(const F2Shape &sh) {
   if (sh.mode & F2_PAIRS) return 1;
-  const char *v = getenv("COFACTOR_F2_WGS");
-  const int w = v ? atoi(v) : 2;
+  static const int w = [] { const char *v = getenv("COFACTOR_F2_WGS"); return v ? atoi(v) : 2; }();   // (read once)
   return w < 1 ? 1 : (w > 3 ? 3 : w);
 }
 

@@ -41,10 +41,15 @@ struct cofactor_ctx {
   // optional HIP-event timing of the two streaming kernels (cofactor_ctx_profile_*)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_ev, cat_ev, fused_ev;
+  const char *last_fused = "";  // name of the one-pass kernel launched last (cofactor_ctx_profile_kernel)
   bool allow_fused = true;      // COFACTOR_NO_FUSED=1 forces the two-kernel path
   int fused_pref = 0;           // COFACTOR_FUSED=1 / 2: only fused_kernel / only fused2_kernel (A/B runs);
                                 // default: fused_kernel where it applies (faster at 10_10), else fused2_kernel
   bool allow_optimistic = true; // COFACTOR_NO_OPTIMISTIC=1: always run the dictionary pass first
+  // experiment knobs, read once when the context is made (never on the update path)
+  bool no_sub = false;          // COFACTOR_NO_SUB=1: no one-hot sub-launches on the code-cache route
+  bool stage_split = false;     // COFACTOR_STAGE_SPLIT=1: one H2D copy per column instead of one per block
+  uint64_t stage_rows_max = 1 << 18;   // COFACTOR_STAGE_ROWS: rows a state's staging buffer may grow to
   unsigned *skip = nullptr;     // optimistic fused pass: [count, tile ids...]
   size_t skip_bytes = 0;
   size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device

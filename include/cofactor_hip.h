@@ -39,6 +39,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define COFACTOR_ABI_VERSION 3
 /* sum_to_triple_<x>_<y> is registered for x,y in 0..20 (the reference registers 0..19,
@@ -85,6 +89,9 @@ void *cofactor_ctx_stream(cofactor_ctx *ctx);
  * figures).  read synchronises the stream, returns the summed kernel milliseconds and launch
  * counts since the previous read, and clears them.  Any output pointer may be NULL. */
 cofactor_status cofactor_ctx_profile_enable(cofactor_ctx *ctx, int on);
+/* Name of the one-pass kernel the context launched last ("fused_kernel", "fused2_kernel",
+ * "fused3_kernel"; "" if none yet): what the `fused` figures of profile_read belong to. */
+const char *cofactor_ctx_profile_kernel(cofactor_ctx *ctx);
 cofactor_status cofactor_ctx_profile_read(cofactor_ctx *ctx, double *gram_ms,
                                           uint64_t *gram_launches, double *cat_ms,
                                           uint64_t *cat_launches, double *fused_ms,
@@ -460,6 +467,9 @@ cofactor_status cofactor_lda_predict_host(cofactor_ctx *ctx, const float *params
                                           int32_t n_num, const int32_t *const *cat, int32_t n_cat,
                                           uint64_t rows, int32_t *out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -66,11 +66,13 @@ struct State {
 // ---- update: Triple::SumNoLift (sum_no_lift.cpp:53-216) and sum_to_nb_agg
 //      (sum_to_nb_agg.cpp:39-146).  `group[i]` plays the role of the per-row state pointer
 //      (state_vector), nullptr = every row goes to states[0].  One call = one DataChunk.
+//      gbase: group is indexed with (i - gbase) — a per-CHUNK pointer vector of 2048 entries, as
+//      DuckDB hands one state vector per chunk (sum_no_lift.cpp:84,94,139 read states[sel[i]] per row).
 template <typename F, typename C>
 static void update_chunk(State<F, C>** states, const int32_t* group, const float* const* num,
                          int n, const int32_t* const* cat, int m, int64_t lo, int64_t hi,
-                         bool nb) {
-  auto st = [&](int64_t i) -> State<F, C>& { return *states[group ? group[i] : 0]; };
+                         bool nb, int64_t gbase = 0) {
+  auto st = [&](int64_t i) -> State<F, C>& { return *states[group ? group[i - gbase] : 0]; };
   for (int64_t i = lo; i < hi; i++) st(i).count += 1;                       // :83-86
   for (int64_t i = lo; i < hi; i++) {                                       // :90-122
     auto& s = st(i);
@@ -419,6 +421,18 @@ static void run_update(State<F, C>** states, const int32_t* group, const float* 
     update_chunk<F, C>(states, group, num, n, cat, m, a, std::min(hi, a + CHUNK), nb);
 }
 
+// The ungrouped aggregate exactly as the executor drives the reference: every chunk comes with a
+// vector of 2048 state pointers (all the same state), read per row.  `chunk_sel` is that vector as
+// indices into `states`; the compiler cannot know its entries are equal, so the accumulator loops
+// keep the reference's per-row indirection instead of turning into plain vector sums
+// ("per-row state-pointer indirection").
+template <typename F, typename C>
+static void run_update_ptr(State<F, C>** states, const int32_t* chunk_sel, const float* const* num, int n,
+                           const int32_t* const* cat, int m, int64_t lo, int64_t hi, bool nb) {
+  for (int64_t a = lo; a < hi; a += CHUNK)
+    update_chunk<F, C>(states, chunk_sel, num, n, cat, m, a, std::min(hi, a + CHUNK), nb, /*gbase=*/a);
+}
+
 }  // namespace orc
 
 using orc::Handle;
@@ -454,18 +468,40 @@ int orc_combine(void* dst, const void* src) {
 
 // Thread-local states over contiguous shards, merged in thread order — DuckDB's model
 // (SURVEY.md §2 "Parallelism strategies").  Used for the CPU baseline.
+// per_row_pointers != 0: through run_update_ptr (a per-chunk state-pointer vector read per row).
+int orc_update_mt_ex(void* state, const float* const* num, int n, const int32_t* const* cat, int m,
+                     int64_t rows, int nb, int threads, int per_row_pointers);
 int orc_update_mt(void* state, const float* const* num, int n, const int32_t* const* cat, int m,
                   int64_t rows, int nb, int threads) {
+  return orc_update_mt_ex(state, num, n, cat, m, rows, nb, threads, 0);
+}
+int orc_update_mt_ex(void* state, const float* const* num, int n, const int32_t* const* cat, int m,
+                     int64_t rows, int nb, int threads, int per_row_pointers) {
   auto* h = (Handle*)state;
   if (threads < 1) threads = 1;
+  // (volatile store: the optimiser must not prove the vector is all zeros)
+  static std::vector<int32_t> chunk_sel;
+  if (per_row_pointers && chunk_sel.empty()) {
+    chunk_sel.assign(orc::CHUNK, 0);
+    volatile int32_t* vs = chunk_sel.data();
+    for (int64_t i = 0; i < orc::CHUNK; i++) vs[i] = 0;
+  }
+  const int32_t* sel = per_row_pointers ? chunk_sel.data() : nullptr;
   std::vector<Handle> local(threads);
   std::vector<std::thread> pool;
   for (int t = 0; t < threads; t++) {
     local[t].mode = h->mode;
     int64_t lo = rows * t / threads, hi = rows * (t + 1) / threads;
     pool.emplace_back([=, &local]() {
-      if (h->mode == 0) { auto* s = &local[t].f; orc::run_update<float, int32_t>(&s, nullptr, num, n, cat, m, lo, hi, nb != 0); }
-      else { auto* s = &local[t].d; orc::run_update<double, int64_t>(&s, nullptr, num, n, cat, m, lo, hi, nb != 0); }
+      if (h->mode == 0) {
+        auto* s = &local[t].f;
+        if (sel) orc::run_update_ptr<float, int32_t>(&s, sel, num, n, cat, m, lo, hi, nb != 0);
+        else orc::run_update<float, int32_t>(&s, nullptr, num, n, cat, m, lo, hi, nb != 0);
+      } else {
+        auto* s = &local[t].d;
+        if (sel) orc::run_update_ptr<double, int64_t>(&s, sel, num, n, cat, m, lo, hi, nb != 0);
+        else orc::run_update<double, int64_t>(&s, nullptr, num, n, cat, m, lo, hi, nb != 0);
+      }
     });
   }
   for (auto& th : pool) th.join();

@@ -34,6 +34,8 @@ def lib():
                                  C.c_int64, C.c_int]
         L.orc_update_mt.argtypes = [C.c_void_p, pp, C.c_int, pp, C.c_int, C.c_int64, C.c_int,
                                     C.c_int]
+        L.orc_update_mt_ex.argtypes = [C.c_void_p, pp, C.c_int, pp, C.c_int, C.c_int64, C.c_int,
+                                       C.c_int, C.c_int]
         L.orc_combine.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_finalize.restype = C.c_int64
         L.orc_finalize.argtypes = [C.c_void_p, C.c_void_p]
@@ -67,13 +69,16 @@ class State:
             lib().orc_state_free(self._h)
             self._h = None
 
-    def update(self, num_cols, cat_cols, nb=False, threads=0):
-        """sum_to_triple_n_m / sum_to_nb_agg_n_m over whole columns (2048-row chunks)."""
+    def update(self, num_cols, cat_cols, nb=False, threads=0, per_row_pointers=False):
+        """sum_to_triple_n_m / sum_to_nb_agg_n_m over whole columns (2048-row chunks).
+        per_row_pointers: every chunk through a vector of 2048 state pointers read per row, as
+        DuckDB's executor drives the reference (bench.py's cpu_baseline)."""
         num, pn = _colptrs(num_cols, np.float32)
         cat, pc = _colptrs(cat_cols, np.int32)
         rows = len(num[0]) if num else (len(cat[0]) if cat else 0)
-        if threads and threads > 0:
-            lib().orc_update_mt(self._h, pn, len(num), pc, len(cat), rows, int(nb), threads)
+        if (threads and threads > 0) or per_row_pointers:
+            lib().orc_update_mt_ex(self._h, pn, len(num), pc, len(cat), rows, int(nb), max(1, int(threads)),
+                                   int(per_row_pointers))
         else:
             st = (C.c_void_p * 1)(self._h)
             lib().orc_update(st, 1, None, pn, len(num), pc, len(cat), rows, int(nb))
