@@ -505,17 +505,18 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
       const unsigned short *tcodes = ctx->code_cache + s_from;
       const uint64_t trows = prows - s_from;
       if (sums_fit) {
+        unsigned subs[COFACTOR_MAX_CAT];
+        int nsub = 0;
         unsigned sub = 0;
         size_t used = 0;
         for (int c = 0; c < L.m; c++) {
           const size_t b = cat_sums_lds_bytes(L, 1u << c, do_s);
-          if (sub && used + b > ctx->lds_budget) {
-            HIP_TRY(launch_cat_sums(tn, tcodes, trows, stride, L, a->D, sub, ctx->cat_grid, st));
-            sub = 0; used = 0;
-          }
+          if (sub && used + b > ctx->lds_budget) { subs[nsub++] = sub; sub = 0; used = 0; }
           sub |= 1u << c; used += b;
         }
-        if (sub) HIP_TRY(launch_cat_sums(tn, tcodes, trows, stride, L, a->D, sub, ctx->cat_grid, st));
+        if (sub) subs[nsub++] = sub;
+        if (nsub == 1) HIP_TRY(launch_cat_sums(tn, tcodes, trows, stride, L, a->D, subs[0], ctx->cat_grid, st));
+        else HIP_TRY(launch_cat_sums_subsets(tn, tcodes, trows, stride, L, a->D, subs, nsub, ctx->cus, st));
       } else {
         CatPass base{};
         base.do_cnt = 1; base.do_s = L.kind == 0;
@@ -570,6 +571,50 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
           used += bytes;
         }
       HIP_TRY(flush());
+      // the big ones: rows binned by the high bits of code 1, slices of the table in LDS (cat.hip);
+      // what that does not take (more than 1024 bins) goes one table at a time with global atomics
+      if (ctx->allow_binned && !big.empty()) {
+        BinPlan plan{};
+        std::vector<int> left;
+        size_t max_part = 0;
+        for (int c1 = 0; c1 < L.m; c1++) {
+          std::vector<int> mine;                    // this column's big pairs
+          for (int qb : big) {
+            int a1 = 0, rem = qb;
+            while (rem >= L.m - a1) { rem -= L.m - a1; a1++; }
+            if (a1 == c1) mine.push_back(qb);
+          }
+          if (mine.empty()) continue;
+          int kc2max = 0;
+          for (int qb : mine) kc2max = std::max(kc2max, L.kc[c1 + (qb - (c1 * L.m - c1 * (c1 - 1) / 2))]);
+          int shift = 0;
+          while ((size_t)(2 << shift) * kc2max * 4 <= ctx->lds_budget && (2 << shift) <= L.kc[c1]) shift++;
+          const int nb = L.kc[c1] >> shift;
+          if ((size_t)(1 << shift) * kc2max * 4 > ctx->lds_budget || nb > 1024 || nb < 1) { left.insert(left.end(), mine.begin(), mine.end()); continue; }
+          const int j = plan.ncols++;
+          plan.col[j] = c1; plan.shift[j] = shift; plan.nb[j] = nb; plan.npart[j] = 0;
+          for (int qb : mine) {
+            const int c2 = c1 + (qb - (c1 * L.m - c1 * (c1 - 1) / 2));
+            const int k = plan.npart[j]++;
+            plan.part[j][k] = c2; plan.part_kc[j][k] = L.kc[c2]; plan.part_poff[j][k] = L.p_off[qb];
+          }
+          max_part = std::max(max_part, (size_t)plan.npart[j]);
+        }
+        if (plan.ncols > 0) {
+          if (!ctx->bin_words) {
+            HIP_TRY(hipMalloc((void **)&ctx->bin_words, bin_scratch_words() * 4));
+            HIP_TRY(hipMemsetAsync(ctx->bin_words, 0, bin_scratch_words() * 4, st));
+            HIP_TRY(hipMalloc((void **)&ctx->bin_plan, sizeof(BinPlan)));
+          }
+          s = scratch_reserve(ctx, ctx->bin_codes, ctx->bin_codes_bytes, (1 + max_part) * stride * 2);
+          if (s != COFACTOR_OK) return s;
+          HIP_TRY(hipMemcpyAsync(ctx->bin_plan, &plan, sizeof(BinPlan), hipMemcpyHostToDevice, st));
+          HIP_TRY(hipStreamSynchronize(st));         // (`plan` lives on this stack frame)
+          HIP_TRY(launch_cat_binned_pairs(tcodes, trows, stride, plan, ctx->bin_plan, ctx->bin_words, ctx->bin_codes, stride,
+                                          ctx->cus, a->D.p, st));
+        }
+        big.swap(left);
+      }
       for (int qb : big) {
         int c1 = 0, rem = qb;
         while (rem >= L.m - c1) { rem -= L.m - c1; c1++; }
@@ -922,6 +967,7 @@ struct PairSource {
   std::vector<std::vector<int32_t>> key_of;
   // sparse pairs (L.sparse_mask): the store's packed keys and counts, already in list order
   std::vector<std::vector<unsigned long long>> skeys, scnt;
+  bool skip_cells = false;                       // the caller reads the pair tables on the device (finalize_on_device)
   const unsigned long long *cells() const { return p_pinned ? p_pinned : p.data(); }
   ~PairSource() { if (p_pinned) (void)hipHostFree(p_pinned); }
 };
@@ -963,7 +1009,8 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
     std::vector<int32_t> code(L.n_slots);
     std::vector<double> sums(std::max(1, L.n_s));
     unsigned long long *p_dst = nullptr;
-    if (L.n_p) {
+    const bool want_cells = L.n_p && !(pair_src && pair_src->skip_cells);
+    if (want_cells) {
       const size_t bytes = sizeof(unsigned long long) * (size_t)L.n_p;
       if (pair_src && bytes >= ((size_t)32 << 20)) {           // big: straight into pinned memory
         HIP_TRY(hipHostMalloc((void **)&pair_src->p_pinned, bytes, hipHostMallocDefault));
@@ -978,7 +1025,7 @@ cofactor_status snapshot(cofactor_agg *a, HostTriple &out, bool dense_only = fal
     HIP_TRY(hipMemcpyAsync(code.data(), a->D.ht_code, sizeof(int32_t) * L.n_slots, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(cnt.data(), a->D.cnt, sizeof(unsigned long long) * L.n_cnt, hipMemcpyDeviceToHost, st));
     if (L.n_s) HIP_TRY(hipMemcpyAsync(sums.data(), a->D.s, sizeof(double) * L.n_s, hipMemcpyDeviceToHost, st));
-    if (L.n_p) HIP_TRY(hipMemcpyAsync(p_dst, a->D.p, sizeof(unsigned long long) * L.n_p, hipMemcpyDeviceToHost, st));
+    if (want_cells) HIP_TRY(hipMemcpyAsync(p_dst, a->D.p, sizeof(unsigned long long) * L.n_p, hipMemcpyDeviceToHost, st));
     int32_t flags[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(flags, a->D.flags, sizeof(flags), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1236,6 +1283,7 @@ cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   ctx->allow_optimistic = env_long("COFACTOR_NO_OPTIMISTIC", 0) == 0;
   ctx->fused_pref = (int)env_long("COFACTOR_FUSED", 0);
   ctx->no_sub = env_long("COFACTOR_NO_SUB", 0) != 0;
+  ctx->allow_binned = env_long("COFACTOR_NO_BINNED", 0) == 0;
   ctx->stage_split = env_long("COFACTOR_STAGE_SPLIT", 0) != 0;
   ctx->stage_rows_max = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
   HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)ctx->gram_grid * GRAM_ACC_LEN));
@@ -1255,6 +1303,11 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->ring_scratch);
   (void)hipFree(ctx->code_cache);
   (void)hipFree(ctx->pair_tmp);
+  (void)hipFree(ctx->fin_dev);
+  if (ctx->fin_host) (void)hipHostFree(ctx->fin_host);
+  (void)hipFree(ctx->bin_words);
+  (void)hipFree(ctx->bin_plan);
+  (void)hipFree(ctx->bin_codes);
   sparse_scratch_free(ctx->sparse_sc);
   for (auto &blk : ctx->stage_pool) {
     if (blk.h_num) (void)hipHostFree(blk.h_num);
@@ -1369,6 +1422,10 @@ cofactor_status cofactor_agg_create(cofactor_ctx *ctx, int n_num, int n_cat, cof
 
 void cofactor_agg_destroy(cofactor_agg *a) {
   if (!a) return;
+  {
+    CTX_LOCK(a->ctx);
+    if (a->ctx->fin_owner == a) a->ctx->fin_owner = nullptr;   // (a later state may reuse the address)
+  }
   CTX_LOCK(a->ctx);
   DeviceGuard guard(a->ctx->device);
   (void)hipStreamSynchronize(a->ctx->stream);
@@ -1522,10 +1579,125 @@ cofactor_status cofactor_agg_update_triples(cofactor_agg *a, const double *blobs
   return COFACTOR_OK;
 }
 
+// finalize of a state with millions of dense pair cells: everything before quad_cat is encoded on the
+// host from the small tables as usual; the quad_cat lists are written by kernels (cat.hip) straight
+// into their place in a device image of the blob and land in a pinned host buffer of the context.
+static cofactor_status finalize_on_device(cofactor_agg *a) {
+  cofactor_ctx *ctx = a->ctx;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  HostTriple snap;
+  PairSource pairs;
+  pairs.skip_cells = true;
+  cofactor_status s = snapshot(a, snap, false, &pairs);
+  if (s != COFACTOR_OK) return s;
+  if ((int)pairs.order.size() != a->m) return fail(COFACTOR_ERR_INTERNAL, "finalize: pair source incomplete");
+  std::vector<double> head;
+  snap.encode_without_pairs(head);
+  const CatLayout &L = pairs.L;
+  const int m = a->m, np = tri(m);
+  // flat arrays: live codes of every column in ascending key order, code -> key per column
+  std::vector<int> order_flat, order_off(m + 1, 0), key_flat(std::max(1, L.n_cnt), 0);
+  for (int c = 0; c < m; c++) {
+    order_flat.insert(order_flat.end(), pairs.order[c].begin(), pairs.order[c].end());
+    order_off[c + 1] = (int)order_flat.size();
+    for (int k = 0; k < L.kc[c]; k++) key_flat[L.cnt_off[c] + k] = pairs.key_of[c][k];
+  }
+  std::vector<PairListInfo> info(np);
+  std::vector<int> row_pair, row_code;
+  std::vector<size_t> first_row(np + 1, 0);
+  {
+    int q = 0;
+    for (int c1 = 0; c1 < m; c1++)
+      for (int c2 = c1; c2 < m; c2++, q++) {
+        info[q] = PairListInfo{(long long)L.p_off[q], L.kc[c2], order_off[c2], order_off[c2 + 1] - order_off[c2], L.cnt_off[c1], L.cnt_off[c2]};
+        first_row[q] = row_pair.size();
+        for (int code : pairs.order[c1]) { row_pair.push_back(q); row_code.push_back(code); }
+      }
+    first_row[np] = row_pair.size();
+  }
+  const int rows = (int)row_pair.size();
+  // device copies of the small arrays (one allocation)
+  const size_t ints = order_flat.size() + key_flat.size() + 2 * (size_t)rows + 16;
+  const size_t bytes = ints * 4 + info.size() * sizeof(PairListInfo) + (size_t)rows * (4 + 8) + 64;
+  unsigned char *d_small = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_small, bytes));
+  auto fail_free = [&](cofactor_status st_) { (void)hipStreamSynchronize(st); (void)hipFree(d_small); return st_; };
+  unsigned char *cur = d_small;
+  auto place = [&](const void *src, size_t n) -> void * {
+    void *at = cur;
+    if (n && src && hipMemcpyAsync(at, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+    cur += (n + 15) / 16 * 16;
+    return at;
+  };
+  PairListInfo *d_info = (PairListInfo *)place(info.data(), info.size() * sizeof(PairListInfo));
+  int *d_order = (int *)place(order_flat.data(), order_flat.size() * 4);
+  int *d_key = (int *)place(key_flat.data(), key_flat.size() * 4);
+  int *d_rp = (int *)place(row_pair.data(), (size_t)rows * 4);
+  int *d_rc = (int *)place(row_code.data(), (size_t)rows * 4);
+  unsigned *d_cnt = (unsigned *)place(nullptr, (size_t)rows * 4);
+  unsigned long long *d_base = (unsigned long long *)place(nullptr, (size_t)rows * 8);
+  if (!d_info || !d_order || !d_key || !d_rp || !d_rc || cur > d_small + bytes + 256) return fail_free(hip_fail(hipGetLastError(), "finalize: upload"));
+  if (launch_pairlist_count(a->D.p, d_rp, d_rc, rows, d_info, d_order, d_cnt, st) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "pairlist_count"));
+  std::vector<unsigned> rowcnt(std::max(1, rows));
+  if (rows && hipMemcpyAsync(rowcnt.data(), d_cnt, (size_t)rows * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "finalize"));
+  if (hipStreamSynchronize(st) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "finalize"));
+  // layout of the pair section: per pair [length, triples...]
+  std::vector<unsigned long long> rowbase(std::max(1, rows));
+  std::vector<size_t> list_at(np), list_len(np, 0);
+  size_t o = 0;
+  for (int q = 0; q < np; q++) {
+    list_at[q] = o++;
+    for (size_t t = first_row[q]; t < first_row[q + 1]; t++) { rowbase[t] = o; o += 3 * (size_t)rowcnt[t]; list_len[q] += rowcnt[t]; }
+  }
+  const size_t total = head.size() + o;
+  if (o > ctx->fin_dev_cap) {
+    (void)hipFree(ctx->fin_dev); ctx->fin_dev = nullptr; ctx->fin_dev_cap = 0;
+    if (hipMalloc((void **)&ctx->fin_dev, o * 8) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "finalize: device blob"));
+    ctx->fin_dev_cap = o;
+  }
+  if (total > ctx->fin_host_cap) {
+    if (ctx->fin_host) (void)hipHostFree(ctx->fin_host);
+    ctx->fin_host = nullptr; ctx->fin_host_cap = 0; ctx->fin_owner = nullptr;
+    const size_t want = total + total / 8;
+    if (hipHostMalloc((void **)&ctx->fin_host, want * 8, hipHostMallocDefault) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "finalize: pinned blob"));
+    ctx->fin_host_cap = want;
+  }
+  ctx->fin_owner = nullptr;
+  if (rows && hipMemcpyAsync(d_base, rowbase.data(), (size_t)rows * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "finalize"));
+  if (launch_pairlist_fill(a->D.p, d_rp, d_rc, rows, d_info, d_order, d_key, d_base, ctx->fin_dev, st) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "pairlist_fill"));
+  if (o && hipMemcpyAsync(ctx->fin_host + head.size(), ctx->fin_dev, o * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "finalize: D2H"));
+  std::memcpy(ctx->fin_host, head.data(), head.size() * 8);         // (meanwhile: the part before quad_cat)
+  if (hipStreamSynchronize(st) != hipSuccess) return fail_free(hip_fail(hipGetLastError(), "finalize"));
+  for (int q = 0; q < np; q++) ctx->fin_host[head.size() + list_at[q]] = (double)list_len[q];
+  (void)hipFree(d_small);
+  ctx->fin_len = total;
+  ctx->fin_owner = a;
+  a->blob_in_ctx = true;
+  a->blob_cache_valid = true;
+  return COFACTOR_OK;
+}
+
 cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap, uint64_t *needed) {
   if (!a) return fail(COFACTOR_ERR_INVALID, "agg is null");
   CTX_LOCK(a->ctx);
+  if (a->blob_cache_valid && a->blob_in_ctx && a->ctx->fin_owner != a) a->blob_cache_valid = false;   // (another state's blob took the buffer)
   if (!a->blob_cache_valid || a->stage_rows > 0) {
+    a->blob_in_ctx = false;
+    {
+      bool host_keys0 = false;
+      for (auto const &c : a->host.col) host_keys0 = host_keys0 || !c.empty();
+      for (auto const &t : a->host.pair) host_keys0 = host_keys0 || !t.empty();
+      // millions of dense pair cells: the lists are written on the device
+      if (a->kind == COFACTOR_TRIPLE && a->m > 0 && !host_keys0 && a->cat_ready && a->dev_dirty && !any_sparse_pair(a->L) &&
+          a->L.n_p >= (1 << 22) && a->ctx->allow_binned) {
+        cofactor_status fs = stage_flush(a);
+        if (fs != COFACTOR_OK) return fs;
+        fs = finalize_on_device(a);
+        if (fs != COFACTOR_OK) return fs;
+        return emit_blob(a->ctx->fin_host, a->ctx->fin_len, out, cap, needed);
+      }
+    }
     HostTriple snap;
     bool host_has_keys = false;       // keys merged in on the host (combine, lifted triples)
     for (auto const &c : a->host.col) host_has_keys = host_has_keys || !c.empty();
@@ -1545,6 +1717,7 @@ cofactor_status cofactor_agg_finalize(cofactor_agg *a, double *out, uint64_t cap
     }
     a->blob_cache_valid = true;
   }
+  if (a->blob_in_ctx) return emit_blob(a->ctx->fin_host, a->ctx->fin_len, out, cap, needed);
   return emit_blob(a->blob_cache.data(), a->blob_cache.size(), out, cap, needed);
 }
 

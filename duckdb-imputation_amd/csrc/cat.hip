@@ -572,11 +572,18 @@ __global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t ro
   }
 }
 
-// counts and sums of the key columns in col_mask (their tables: cnt u32 [kc], then s f64 [kc][n])
+// counts and sums of the key columns in col_mask (their tables: cnt u32 [kc], then s f64 [kc][n]).
+// subs.n > 0: ONE launch for several column subsets whose tables do not fit LDS together — workgroup
+// b serves subset b % subs.n over the rows of row group b / subs.n, so the subs.n workgroups that
+// read the same rows run side by side and the numeric columns come from HBM once (the others hit
+// L2 / the Infinity Cache) instead of once per subset: 10 launches of 4.2 GB each at K = 1000.
+struct SumSubsets { int n; unsigned mask[COFACTOR_MAX_CAT]; };
 __global__ __launch_bounds__(CAT_THREADS) void cat_sums_kernel(NumCols num, const unsigned short *__restrict__ codes, uint64_t rows,
                                                                uint64_t stride, CatLayout L, CatDevice D, unsigned col_mask,
-                                                               int do_s) {
+                                                               int do_s, SumSubsets subs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if (subs.n > 0) { col_mask = subs.mask[bid % subs.n]; bid /= subs.n; nblk /= subs.n; }
   // LDS carve: sums first (8-byte aligned), then counts
   __shared__ int s_base[COFACTOR_MAX_CAT], c_base[COFACTOR_MAX_CAT];
   __shared__ int tot_s, tot_c;
@@ -593,8 +600,8 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_sums_kernel(NumCols num, cons
   for (int i = tid; i < tot_s; i += CAT_THREADS) l_s[i] = 0.0;
   for (int i = tid; i < tot_c; i += CAT_THREADS) l_c[i] = 0u;
   __syncthreads();
-  const uint64_t step = (uint64_t)gridDim.x * CAT_THREADS;
-  for (uint64_t r = (uint64_t)blockIdx.x * CAT_THREADS + tid; r < rows; r += step) {
+  const uint64_t step = (uint64_t)nblk * CAT_THREADS;
+  for (uint64_t r = (uint64_t)bid * CAT_THREADS + tid; r < rows; r += step) {
     float x[COFACTOR_MAX_NUM];
     if (do_s)
 #pragma unroll
@@ -732,7 +739,33 @@ hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint
   }
   const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
   if ((uint64_t)grid > need) grid = (int)need;
-  hipLaunchKernelGGL(cat_sums_kernel, dim3(grid), dim3(CAT_THREADS), lds, stream, num, codes, rows, stride, L, D, col_mask, do_s ? 1 : 0);
+  hipLaunchKernelGGL(cat_sums_kernel, dim3(grid), dim3(CAT_THREADS), lds, stream, num, codes, rows, stride, L, D, col_mask, do_s ? 1 : 0,
+                     SumSubsets{});
+  return hipGetLastError();
+}
+
+hipError_t launch_cat_sums_subsets(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
+                                   const CatLayout &L, const CatDevice &D, const unsigned *masks, int nsub, int cus,
+                                   hipStream_t stream) {
+  if (rows == 0 || nsub <= 0) return hipSuccess;
+  if (nsub > COFACTOR_MAX_CAT) return hipErrorInvalidValue;
+  const bool do_s = L.kind == 0 && L.n > 0;
+  SumSubsets subs{};
+  subs.n = nsub;
+  size_t lds = 0;
+  for (int i = 0; i < nsub; i++) { subs.mask[i] = masks[i]; lds = std::max(lds, cat_sums_lds_bytes(L, masks[i], do_s)); }
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)cat_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  // all workgroups resident at once (one per CU when the tables take most of its LDS), so that the
+  // subsets of a row group really run side by side
+  const int per_cu = std::max(1, (int)std::min<size_t>(4, (150 * 1024) / std::max<size_t>(lds, 1)));
+  int groups = std::max(1, cus * per_cu / nsub);
+  const uint64_t need = (rows + CAT_THREADS - 1) / CAT_THREADS;
+  if ((uint64_t)groups > need) groups = (int)need;
+  hipLaunchKernelGGL(cat_sums_kernel, dim3(groups * nsub), dim3(CAT_THREADS), lds, stream, num, codes, rows, stride, L, D, 0u,
+                     do_s ? 1 : 0, subs);
   return hipGetLastError();
 }
 
@@ -757,6 +790,312 @@ hipError_t launch_cat_pairs(const unsigned short *codes, uint64_t rows, uint64_t
     }
     if (e != hipSuccess) return e;
   }
+  return hipGetLastError();
+}
+
+// ---- pair tables too big for LDS: rows BINNED by the high bits of code 1 (round 3) ------------------------
+// cat_pair_hbm_kernel does one global atomic per row and pair into a 4 MB table: 2.7e10 atomics/s, the
+// chip's rate for scattered 4-byte atomics, 1.86 ms per pair and 5e7 rows at K = 1000 (72 % of that
+// step).  LDS atomics are ~100x faster but a 1024 x 1024 table does not fit.  A SLICE of it does:
+// `sb` rows of code 1 x all kc2 codes of column 2 (32 x 1024 u32 = 128 KB).  So, per column c1 that
+// has such pairs:
+//   cat_bin_count_kernel    histogram of (code1 >> shift) over the piece (all c1 in one launch)
+//   cat_bin_scan_kernel     bin offsets = exclusive scan; cursors start at the offsets
+//   cat_bin_scatter_kernel  rows regrouped bin by bin: the low bits of code 1 and the codes of every
+//                           partner column c2, staged through LDS so that each bin's run of a
+//                           workgroup's chunk leaves as contiguous 2-byte stores
+//   cat_pair_bin_kernel     one workgroup per (pair, bin[, split]): its slice in LDS, ds_add_u32 per
+//                           row, the slice added to the u64 table at the end (plain adds: a cell
+//                           belongs to one bin)
+// Traffic: the partner codes are read and written once per c1 (2 B each) and read once per pair.
+constexpr int BIN_CHUNK = 8192;                 // rows of a scatter workgroup's chunk (32 per thread, 8 quads)
+constexpr int BIN_MAX = 1024;                   // bins per column at most (LDS histograms)
+
+__global__ __launch_bounds__(256) void cat_bin_count_kernel(const unsigned short *__restrict__ codes, uint64_t rows,
+                                                            uint64_t stride, const BinPlan *__restrict__ planp,
+                                                            unsigned *__restrict__ hist) {
+  const BinPlan &plan = *planp;
+  __shared__ unsigned l_hist[BIN_MAX];
+  for (int j = 0; j < plan.ncols; j++) {
+    const int nb = plan.nb[j], shift = plan.shift[j];
+    const unsigned short *col = codes + (uint64_t)plan.col[j] * stride;
+    for (int i = threadIdx.x; i < nb; i += 256) l_hist[i] = 0u;
+    __syncthreads();
+    const uint64_t nq = (rows + 3) / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (uint64_t)gridDim.x * 256) {
+      const uint2 a = *reinterpret_cast<const uint2 *>(col + 4 * q);     // (rows past the end hold CODE_NONE)
+      const unsigned c[4] = {a.x & 0xFFFFu, a.x >> 16, a.y & 0xFFFFu, a.y >> 16};
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (c[e] != CODE_NONE) atomicAdd(&l_hist[c[e] >> shift], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 256)
+      if (l_hist[i]) atomicAdd(&hist[j * BIN_MAX + i], l_hist[i]);
+    __syncthreads();
+  }
+}
+
+// off[j][0..nb] = exclusive scan of hist[j][..]; cursor[j][b] = off[j][b]; hist is cleared for the next piece
+__global__ __launch_bounds__(64) void cat_bin_scan_kernel(const BinPlan *__restrict__ planp, unsigned *__restrict__ hist,
+                                                          unsigned *__restrict__ off, unsigned *__restrict__ cursor) {
+  const BinPlan &plan = *planp;
+  const int j = blockIdx.x;
+  if (threadIdx.x != 0 || j >= plan.ncols) return;
+  unsigned run = 0;
+  for (int b = 0; b < plan.nb[j]; b++) {
+    off[j * (BIN_MAX + 1) + b] = run;
+    cursor[j * BIN_MAX + b] = run;
+    run += hist[j * BIN_MAX + b];
+    hist[j * BIN_MAX + b] = 0u;
+  }
+  off[j * (BIN_MAX + 1) + plan.nb[j]] = run;
+}
+
+// out[0][pos] = code1 & (sb - 1), out[1 + i][pos] = code of partner column i, pos = the row's place in
+// its bin (bin-major).  One chunk of BIN_CHUNK rows per workgroup and step.
+__global__ __launch_bounds__(256) void cat_bin_scatter_kernel(const unsigned short *__restrict__ codes, uint64_t rows,
+                                                              uint64_t stride, const BinPlan *__restrict__ planp, int j,
+                                                              unsigned *__restrict__ cursor,
+                                                              unsigned short *__restrict__ out, uint64_t out_stride) {
+  const BinPlan &plan = *planp;
+  __shared__ unsigned l_cnt[BIN_MAX], l_off[BIN_MAX], l_base[BIN_MAX];
+  __shared__ unsigned l_gpos[BIN_CHUNK];
+  __shared__ unsigned short l_stage[BIN_CHUNK];
+  const int nb = plan.nb[j], shift = plan.shift[j], tid = threadIdx.x;
+  const unsigned lowmask = (1u << shift) - 1u;
+  const unsigned short *col1 = codes + (uint64_t)plan.col[j] * stride;
+  unsigned *cur = cursor + j * BIN_MAX;
+  constexpr int PER = BIN_CHUNK / 256;
+  const uint64_t nchunks = (rows + BIN_CHUNK - 1) / BIN_CHUNK;
+  for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const uint64_t r0 = ch * BIN_CHUNK;
+    for (int i = tid; i < nb; i += 256) l_cnt[i] = 0u;
+    __syncthreads();
+    // a thread's rows: quads r0 + 4 (q 256 + tid) .. + 3 (8-byte loads; rows past the end hold CODE_NONE)
+    unsigned code1[PER], rank[PER];
+#pragma unroll
+    for (int q = 0; q < PER / 4; q++) {
+      const uint64_t r = r0 + 4 * ((uint64_t)q * 256 + tid);
+      uint2 v = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (r < stride) v = *reinterpret_cast<const uint2 *>(col1 + r);
+      code1[4 * q] = v.x & 0xFFFFu; code1[4 * q + 1] = v.x >> 16; code1[4 * q + 2] = v.y & 0xFFFFu; code1[4 * q + 3] = v.y >> 16;
+    }
+#pragma unroll
+    for (int e = 0; e < PER; e++) rank[e] = code1[e] != CODE_NONE ? atomicAdd(&l_cnt[code1[e] >> shift], 1u) : 0u;
+    __syncthreads();
+    if (tid < 64) {                                   // one wave: exclusive scan of the bin counts + global reservation
+      unsigned carry = 0;
+      for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int b = b0 + tid;
+        const unsigned v = b < nb ? l_cnt[b] : 0u;
+        unsigned incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (tid >= d) incl += o; }
+        if (b < nb) {
+          l_off[b] = carry + incl - v;
+          l_base[b] = v ? atomicAdd(&cur[b], v) : 0u;
+        }
+        carry += __shfl(incl, 63, 64);
+      }
+    }
+    __syncthreads();
+    unsigned slot[PER];
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+      slot[e] = 0xFFFFFFFFu;
+      if (code1[e] != CODE_NONE) {
+        const unsigned b = code1[e] >> shift;
+        slot[e] = l_off[b] + rank[e];
+        l_gpos[slot[e]] = l_base[b] + rank[e];
+      }
+    }
+    unsigned total = 0;
+    {
+      const int last = nb - 1;
+      __syncthreads();
+      total = l_off[last] + l_cnt[last];
+    }
+    for (int k = 0; k <= plan.npart[j]; k++) {        // column 0: low bits of code 1; then the partner columns
+      const unsigned short *src = k == 0 ? nullptr : codes + (uint64_t)plan.part[j][k - 1] * stride;
+#pragma unroll
+      for (int q = 0; q < PER / 4; q++) {
+        const uint64_t r = r0 + 4 * ((uint64_t)q * 256 + tid);
+        uint2 v = make_uint2(0u, 0u);
+        if (k != 0 && r < stride) v = *reinterpret_cast<const uint2 *>(src + r);
+        const unsigned val[4] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16};
+#pragma unroll
+        for (int j4 = 0; j4 < 4; j4++) {
+          const int e = 4 * q + j4;
+          if (slot[e] != 0xFFFFFFFFu) l_stage[slot[e]] = k == 0 ? (unsigned short)(code1[e] & lowmask) : (unsigned short)val[j4];
+        }
+      }
+      __syncthreads();
+      unsigned short *dst = out + (uint64_t)k * out_stride;
+      // two staged elements per thread and step: one 4-byte store when they are neighbours in the
+      // same bin run at an even position (most are: a chunk's run per bin is ~ BIN_CHUNK / nb long)
+      for (unsigned i = 2 * tid; i < total; i += 512) {
+        const unsigned g0 = l_gpos[i];
+        if (i + 1 < total) {
+          const unsigned g1 = l_gpos[i + 1];
+          if (g1 == g0 + 1 && !(g0 & 1u)) {
+            *reinterpret_cast<unsigned *>(dst + g0) = (unsigned)l_stage[i] | ((unsigned)l_stage[i + 1] << 16);
+          } else {
+            dst[g0] = l_stage[i];
+            dst[g1] = l_stage[i + 1];
+          }
+        } else {
+          dst[g0] = l_stage[i];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// One workgroup per (partner k, bin b, split s) of column plan.col[j]: the rows of the bin's s-th part,
+// slice [sb][kc2] of the pair table in LDS.
+__global__ __launch_bounds__(1024) void cat_pair_bin_kernel(const unsigned short *__restrict__ binned, uint64_t out_stride,
+                                                            const BinPlan *__restrict__ planp, int j,
+                                                            const unsigned *__restrict__ off, int splits,
+                                                            unsigned long long *__restrict__ p) {
+  const BinPlan &plan = *planp;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bin_lds[];
+  unsigned *slice = reinterpret_cast<unsigned *>(bin_lds);
+  const int nb = plan.nb[j], sb = 1 << plan.shift[j];
+  const int s = blockIdx.x % splits, b = (blockIdx.x / splits) % nb, k = blockIdx.x / (splits * nb);
+  const int kc2 = plan.part_kc[j][k], kbits = 31 - __builtin_clz(kc2);
+  const int cells = sb * kc2;
+  for (int i = threadIdx.x; i < cells; i += 1024) slice[i] = 0u;
+  __syncthreads();
+  const unsigned *o = off + j * (BIN_MAX + 1);
+  const uint64_t lo = o[b], hi = o[b + 1], len = hi - lo;
+  const uint64_t a = lo + len * s / splits, e = lo + len * (s + 1) / splits;
+  const unsigned short *c1 = binned, *c2 = binned + (uint64_t)(1 + k) * out_stride;
+  // the body in quads of rows from an 8-byte aligned start, head and tail row by row
+  uint64_t r = a;
+  const uint64_t body0 = min(e, (a + 3) / 4 * 4), body1 = body0 + (e > body0 ? (e - body0) / 4 * 4 : 0);
+  for (uint64_t i = r + threadIdx.x; i < body0; i += 1024) atomicAdd(&slice[((unsigned)c1[i] << kbits) + c2[i]], 1u);
+  for (uint64_t q = body0 / 4 + threadIdx.x; q < body1 / 4; q += 1024) {
+    const uint2 x = *reinterpret_cast<const uint2 *>(c1 + 4 * q), y = *reinterpret_cast<const uint2 *>(c2 + 4 * q);
+    atomicAdd(&slice[((x.x & 0xFFFFu) << kbits) + (y.x & 0xFFFFu)], 1u);
+    atomicAdd(&slice[((x.x >> 16) << kbits) + (y.x >> 16)], 1u);
+    atomicAdd(&slice[((x.y & 0xFFFFu) << kbits) + (y.y & 0xFFFFu)], 1u);
+    atomicAdd(&slice[((x.y >> 16) << kbits) + (y.y >> 16)], 1u);
+  }
+  for (uint64_t i = body1 + threadIdx.x; i < e; i += 1024) atomicAdd(&slice[((unsigned)c1[i] << kbits) + c2[i]], 1u);
+  __syncthreads();
+  unsigned long long *tab = p + plan.part_poff[j][k] + (uint64_t)b * (uint64_t)cells;   // rows [b sb, (b+1) sb) of the table
+  for (int i = threadIdx.x; i < cells; i += 1024) {
+    const unsigned v = slice[i];
+    if (v) {
+      if (splits > 1) atomicAdd(&tab[i], (unsigned long long)v);
+      else tab[i] += v;
+    }
+  }
+}
+
+size_t bin_scratch_words() { return (size_t)COFACTOR_MAX_CAT * (3 * BIN_MAX + 1); }
+
+hipError_t launch_cat_binned_pairs(const unsigned short *codes, uint64_t rows, uint64_t stride, const BinPlan &plan,
+                                   const BinPlan *d_plan, unsigned *scratch, unsigned short *binned, uint64_t out_stride,
+                                   int cus, unsigned long long *p, hipStream_t stream) {
+  if (rows == 0 || plan.ncols == 0) return hipSuccess;
+  unsigned *hist = scratch, *off = hist + COFACTOR_MAX_CAT * BIN_MAX, *cursor = off + COFACTOR_MAX_CAT * (BIN_MAX + 1);
+  const int grid = (int)std::min<uint64_t>((uint64_t)cus * 8, (rows / 4 + 255) / 256);
+  hipLaunchKernelGGL(cat_bin_count_kernel, dim3(std::max(1, grid)), dim3(256), 0, stream, codes, rows, stride, d_plan, hist);
+  hipLaunchKernelGGL(cat_bin_scan_kernel, dim3(plan.ncols), dim3(64), 0, stream, d_plan, hist, off, cursor);
+  hipError_t e = hipGetLastError();
+  for (int j = 0; j < plan.ncols && e == hipSuccess; j++) {
+    const int sgrid = (int)std::min<uint64_t>((uint64_t)cus * 4, (rows + BIN_CHUNK - 1) / BIN_CHUNK);
+    hipLaunchKernelGGL(cat_bin_scatter_kernel, dim3(std::max(1, sgrid)), dim3(256), 0, stream, codes, rows, stride, d_plan, j,
+                       cursor, binned, out_stride);
+    int max_cells = 0;
+    for (int k = 0; k < plan.npart[j]; k++) max_cells = std::max(max_cells, (1 << plan.shift[j]) * plan.part_kc[j][k]);
+    const size_t lds = (size_t)max_cells * 4;
+    int splits = 1;
+    while (plan.npart[j] * plan.nb[j] * splits < 2 * cus && splits < 8) splits *= 2;
+    if ((e = hipFuncSetAttribute((const void *)cat_pair_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) break;
+    hipLaunchKernelGGL(cat_pair_bin_kernel, dim3(plan.npart[j] * plan.nb[j] * splits), dim3(1024), lds, stream, binned, out_stride,
+                       d_plan, j, off, splits, p);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+// ---- finalize: the quad_cat lists written on the device (SumStateFinalize, sum_state.cpp:440-461) ---------
+// One workgroup per table row in ascending key order (row t = code `row_code[t]` of pair `row_pair[t]`):
+//   pairlist_count_kernel   non-zero cells of the row among the live codes of column 2
+//   pairlist_fill_kernel    (key1, key2, count) triples as doubles at rowbase[t], in ascending key2
+// The host only turns 55 000 row counts into offsets; the 5.5e7 cells of a K = 1000 state never
+// cross PCIe as a 440 MB table to be re-encoded by host threads, they arrive as the finished list.
+__global__ __launch_bounds__(256) void pairlist_count_kernel(const unsigned long long *__restrict__ p,
+                                                             const int *__restrict__ row_pair, const int *__restrict__ row_code,
+                                                             const PairListInfo *__restrict__ info,
+                                                             const int *__restrict__ order_flat, unsigned *__restrict__ rowcnt) {
+  const int t = blockIdx.x;
+  const PairListInfo pi = info[row_pair[t]];
+  const unsigned long long *row = p + pi.p_off + (long long)row_code[t] * pi.kc2;
+  const int *o2 = order_flat + pi.o2_off;
+  unsigned nz = 0;
+  for (int j = threadIdx.x; j < pi.o2_len; j += 256) nz += row[o2[j]] != 0ull;
+  for (int off = 32; off > 0; off >>= 1) nz += __shfl_down(nz, off, 64);
+  __shared__ unsigned part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = nz;
+  __syncthreads();
+  if (threadIdx.x == 0) rowcnt[t] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void pairlist_fill_kernel(const unsigned long long *__restrict__ p,
+                                                            const int *__restrict__ row_pair, const int *__restrict__ row_code,
+                                                            const PairListInfo *__restrict__ info,
+                                                            const int *__restrict__ order_flat, const int *__restrict__ key_flat,
+                                                            const unsigned long long *__restrict__ rowbase,
+                                                            double *__restrict__ out) {
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const PairListInfo pi = info[row_pair[t]];
+  const int code1 = row_code[t];
+  const unsigned long long *row = p + pi.p_off + (long long)code1 * pi.kc2;
+  const int *o2 = order_flat + pi.o2_off;
+  const double key1 = (double)key_flat[pi.k1_off + code1];
+  double *w = out + rowbase[t];
+  __shared__ unsigned wsum[4];
+  __shared__ unsigned carry;
+  if (tid == 0) carry = 0u;
+  __syncthreads();
+  for (int j0 = 0; j0 < pi.o2_len; j0 += 256) {
+    const int j = j0 + tid;
+    int code2 = 0;
+    unsigned long long v = 0ull;
+    if (j < pi.o2_len) { code2 = o2[j]; v = row[code2]; }
+    const unsigned flag = v != 0ull;
+    unsigned incl = flag;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned before = carry;
+    for (int k = 0; k < wv; k++) before += wsum[k];
+    if (flag) {
+      double *e = w + 3ull * (before + incl - 1u);
+      e[0] = key1; e[1] = (double)key_flat[pi.k2_off + code2]; e[2] = (double)v;
+    }
+    __syncthreads();
+    if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+
+hipError_t launch_pairlist_count(const unsigned long long *p, const int *row_pair, const int *row_code, int rows,
+                                 const PairListInfo *info, const int *order_flat, unsigned *rowcnt, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(pairlist_count_kernel, dim3(rows), dim3(256), 0, stream, p, row_pair, row_code, info, order_flat, rowcnt);
+  return hipGetLastError();
+}
+hipError_t launch_pairlist_fill(const unsigned long long *p, const int *row_pair, const int *row_code, int rows,
+                                const PairListInfo *info, const int *order_flat, const int *key_flat,
+                                const unsigned long long *rowbase, double *out, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(pairlist_fill_kernel, dim3(rows), dim3(256), 0, stream, p, row_pair, row_code, info, order_flat, key_flat,
+                     rowbase, out);
   return hipGetLastError();
 }
 

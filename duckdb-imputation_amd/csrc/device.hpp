@@ -136,10 +136,39 @@ hipError_t launch_cat_codes(const CatCols &cat, uint64_t rows, uint64_t stride, 
 size_t cat_sums_lds_bytes(const CatLayout &L, unsigned col_mask, bool do_s);
 hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
                            const CatLayout &L, const CatDevice &D, unsigned col_mask, int grid, hipStream_t stream);
+// several column subsets (each fits LDS on its own) in ONE launch: the rows are read from HBM once
+hipError_t launch_cat_sums_subsets(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
+                                   const CatLayout &L, const CatDevice &D, const unsigned *masks, int nsub, int cus,
+                                   hipStream_t stream);
 // gtab == nullptr: LDS tables for the pairs of P (cells [p_base, p_base + p_cells)); else ONE pair, u32 cells in gtab
 hipError_t launch_cat_pairs(const unsigned short *codes, uint64_t rows, uint64_t stride, const CatLayout &L, const CatDevice &D,
                             const CatPass &P, unsigned *gtab, int grid, hipStream_t stream);
 hipError_t launch_cat_fold_u32(const unsigned *src, long long cells, unsigned long long *dst, hipStream_t stream);
+
+// finalize's quad_cat lists written on the device (cat.hip): per dense pair where its table sits and
+// where the live codes of column 2 (ascending key order) and the code -> key maps are in the flat arrays
+struct PairListInfo { long long p_off; int kc2, o2_off, o2_len, k1_off, k2_off; };
+hipError_t launch_pairlist_count(const unsigned long long *p, const int *row_pair, const int *row_code, int rows,
+                                 const PairListInfo *info, const int *order_flat, unsigned *rowcnt, hipStream_t stream);
+hipError_t launch_pairlist_fill(const unsigned long long *p, const int *row_pair, const int *row_code, int rows,
+                                const PairListInfo *info, const int *order_flat, const int *key_flat,
+                                const unsigned long long *rowbase, double *out, hipStream_t stream);
+
+// Pair tables too big for LDS, rows binned by the high bits of code 1 (cat.hip): for every column
+// col[j] that has such pairs, its partner columns part[j][0..npart) (code capacity part_kc, table at
+// p + part_poff), bins of 2^shift codes (nb bins: nb << shift = the column's code capacity).
+struct BinPlan {
+  int ncols;
+  int col[COFACTOR_MAX_CAT], shift[COFACTOR_MAX_CAT], nb[COFACTOR_MAX_CAT], npart[COFACTOR_MAX_CAT];
+  int part[COFACTOR_MAX_CAT][COFACTOR_MAX_CAT], part_kc[COFACTOR_MAX_CAT][COFACTOR_MAX_CAT];
+  long long part_poff[COFACTOR_MAX_CAT][COFACTOR_MAX_CAT];
+};
+size_t bin_scratch_words();                       // u32 words of `scratch` (zeroed once by the caller)
+// codes: the piece's 16-bit code cache; binned: (1 + max npart) x out_stride u16 scratch
+// d_plan: the same plan in device memory (it is past the kernel-argument size)
+hipError_t launch_cat_binned_pairs(const unsigned short *codes, uint64_t rows, uint64_t stride, const BinPlan &plan,
+                                   const BinPlan *d_plan, unsigned *scratch, unsigned short *binned, uint64_t out_stride,
+                                   int cus, unsigned long long *p, hipStream_t stream);
 
 // Dictionary-aligned table seam (multi-GPU): re-index tables by a code remap, and the tables as one
 // array of doubles [cnt | s | p] (n_cnt + n_s + n_p values) for a single all-reduce.

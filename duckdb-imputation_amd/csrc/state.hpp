@@ -62,6 +62,18 @@ struct cofactor_ctx {
   size_t code_cache_bytes = 0;
   unsigned *pair_tmp = nullptr;
   size_t pair_tmp_bytes = 0;
+  // binned pair tables (cat.hip): histogram / offset / cursor words and the regrouped code columns
+  unsigned *bin_words = nullptr;
+  cofactor::BinPlan *bin_plan = nullptr;   // device copy of the piece's plan
+  unsigned short *bin_codes = nullptr;
+  size_t bin_codes_bytes = 0;
+  // finalize of states with millions of pair cells: the lists are written on the device into fin_dev
+  // and land in the pinned host buffer fin_host (both grown on demand, kept); fin_owner / fin_epoch say
+  // whose blob the pinned buffer currently holds
+  double *fin_dev = nullptr, *fin_host = nullptr;
+  size_t fin_dev_cap = 0, fin_host_cap = 0, fin_len = 0;
+  const void *fin_owner = nullptr;
+  bool allow_binned = true;     // COFACTOR_NO_BINNED=1: big pair tables by global atomics (round 2's path)
   cofactor::SparseScratch sparse_sc;   // sort / merge buffers of the sparse pair tables
   // Staging blocks (pinned + device, both buffers of a state) handed back by states that were
   // destroyed or outgrew them, reused by the next state of the same shape: the worker threads of
@@ -88,6 +100,7 @@ struct cofactor_agg {
   // finalize's two-call protocol: the blob of the size query is kept for the fill call
   BlobVec blob_cache;
   bool blob_cache_valid = false;
+  bool blob_in_ctx = false;     // the valid blob sits in ctx->fin_host (device-encoded pair lists), not in blob_cache
   // pair tables kept as sorted lists (L.sparse_mask): one store per column pair, empty for dense pairs
   std::vector<cofactor::SparseStore> sparse;
   cofactor::CatLayout L{};
