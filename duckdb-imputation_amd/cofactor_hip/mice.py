@@ -22,8 +22,9 @@ class MiceTable:
     """Columns of one shard: float32 numeric and int32 key tensors on the GPU, and for every
     incomplete column a uint8 tensor that is 1 where the value is missing."""
 
-    def __init__(self, num, cat, num_null=None, cat_null=None):
+    def __init__(self, num, cat, num_null=None, cat_null=None, first_row=0):
         self.num, self.cat = dict(num), dict(cat)
+        self.first_row = int(first_row)      # index of this shard's first row in the whole table
         self.num_null, self.cat_null = dict(num_null or {}), dict(cat_null or {})
         # WHERE col_IS_NULL IS FALSE wants the complement; the masks never change during a run
         self.num_keep = {k: (v == 0).to(v.dtype) for k, v in self.num_null.items()}
@@ -71,7 +72,6 @@ def run_mice(ctx, table, iterations=1, dist=None, device=None, seed=0, shrinkage
     (stochastic linear regression, :85-142), `iterations` times.  Fills the table in place and
     returns the parameter vectors of the last iteration per column."""
     import torch
-    rank = dist.get_rank() if dist is not None else 0
     num_names, cat_names = list(table.num), list(table.cat)
     n, m = len(num_names), len(cat_names)
     t_log = timings if timings is not None else {}
@@ -107,7 +107,12 @@ def run_mice(ctx, table, iterations=1, dist=None, device=None, seed=0, shrinkage
                     label = num_names.index(name)
                     params = linreg_train(triple, label, step_size, 0.0, max_iterations, True, False)
                     t2 = clock()
-                    col_seed = (seed * 1000003 + it * 10007 + label * 101 + rank * 7919 + 1) & (2 ** 63 - 1)
+                    # the noise of a row is a function of (seed, GLOBAL row index): the kernel hashes
+                    # seed + GOLDEN * (row + 1), so a shard that starts at row `first_row` of the table
+                    # passes seed + GOLDEN * first_row and every row draws what it would draw in a
+                    # one-GPU run, however the table is sharded (no rank term)
+                    col_seed = (seed * 1000003 + it * 10007 + label * 101 + 1) & (2 ** 63 - 1)
+                    col_seed = (col_seed + 0x9E3779B97F4A7C15 * table.first_row) & (2 ** 64 - 1)
                     ctx.linreg_predict(params, [table.num[c] for c in num_names if c != name],
                                        [table.cat[c] for c in cat_names], out=table.num[name],
                                        mask=table.num_null[name], noise=True, seed=col_seed)

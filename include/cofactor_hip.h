@@ -431,8 +431,10 @@ cofactor_status cofactor_lda_train(const double *triple, uint64_t triple_len, in
 /* linreg_predict — ML::linreg_impute (regression.cpp:397-508): per row intercept + coef . x +
  * the coefficient of each key column's key (a key the model never saw adds 0), optionally plus
  * N(0, params[last]) noise.  The reference draws the noise from random() seeded off
- * /dev/urandom; here it is a counter-based generator of (seed, row), so a run is reproducible and
- * independent of the sharding.  d_num[n_num] are the feature columns in training order WITHOUT
+ * /dev/urandom; here it is a counter-based generator of (seed, row): row i of the call draws
+ * hash(seed + 0x9E3779B97F4A7C15 * (i + 1)).  A run is reproducible, and independent of the sharding
+ * when a rank whose columns start at row `first` of the whole table passes
+ * seed + 0x9E3779B97F4A7C15 * first (mod 2^64), as cofactor_hip/mice.py does.  d_num[n_num] are the feature columns in training order WITHOUT
  * the label, d_cat[n_cat] every key column.  d_mask (optional, one byte per row): only rows with
  * a non-zero byte are written — `CASE WHEN col_IS_NULL THEN linreg_predict(..) ELSE col END`
  * (imputation/algorithms/imputation_base.cpp:137) as an in-place column update. */

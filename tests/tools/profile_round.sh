@@ -24,11 +24,11 @@ if [ "$2" = "rest" ]; then
     && run 10_10_k1000 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 1000 && echo rest collected
   exit 0
 fi
-KEY=gram_kernel_20_0 KROWS=1000000000 run 20_0 && KEY=fused_kernel_10_10 KROWS=100000000 run 10_10 --total-rows 1e8 --num-cols 10 --cat-cols 10 && KEY=fused_kernel_nb_10_10 KROWS=100000000 run nb_10_10 --total-rows 1e8 --num-cols 10 --cat-cols 10 --nb \
+KEY=gram_kernel_20_0 KROWS=1000000000 run 20_0 && KEY=fused3_kernel_10_10 KROWS=100000000 run 10_10 --total-rows 1e8 --num-cols 10 --cat-cols 10 && KEY=fused2_kernel_nb_10_10 KROWS=100000000 run nb_10_10 --total-rows 1e8 --num-cols 10 --cat-cols 10 --nb \
   && KEY="" run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && run 20_20 --total-rows 5e7 --num-cols 20 --cat-cols 20 \
   && run 20_10 --total-rows 5e7 --num-cols 20 --cat-cols 10 && run 16_0 --total-rows 1e9 --num-cols 16 \
-  && run 10_10_k1000 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 1000 \
+  && run 10_10_k1000 --total-rows 1e8 --num-cols 10 --cat-cols 10 --keys 1000 \
   && sh $R/tests/tools/sq_counters.sh ${TAG}_gram_20_0 gram_kernel \
-  && sh $R/tests/tools/sq_counters.sh ${TAG}_fused_10_10 fused_kernel --total-rows 1e8 --num-cols 10 --cat-cols 10 \
+  && sh $R/tests/tools/sq_counters.sh ${TAG}_fused3_10_10 fused3_kernel --total-rows 1e8 --num-cols 10 --cat-cols 10 \
   && sh $R/tests/tools/sq_counters.sh ${TAG}_fused2_nb_10_10 fused2_kernel --total-rows 1e8 --num-cols 10 --cat-cols 10 --nb \
   && echo profiles collected
