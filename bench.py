@@ -214,8 +214,23 @@ def main():
     if use_dist:
         collective = "torch.distributed all_reduce (%s)" % dist.get_backend()
         if args.collective == "lib" and not args.rehearse_one_gpu:
-            comm = cdist.make_comm(ctx, dist)
-            collective = "cofactor_agg_allreduce: ncclAllReduce on the library's communicator (csrc/comm.cpp)"
+            # every rank tries; the ranks then agree (one tiny torch all-reduce) whether ALL of them have
+            # a communicator — a rank on its own inside the library's collective would hang the job
+            err = None
+            try:
+                comm = cdist.make_comm(ctx, dist)
+            except Exception as e:                   # noqa: BLE001 - reported in the JSON line
+                err = e
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                collective = "cofactor_agg_allreduce: ncclAllReduce on the library's communicator (csrc/comm.cpp)"
+            else:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                collective += "; the library's communicator could not be made on every rank%s" % (
+                    "" if err is None else " (this rank: %s)" % err)
 
     def step():
         agg.reset()
