@@ -672,9 +672,12 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
   // fused2_kernel (LDS-DMA ring, everything on MFMA) for what it does not take: NB aggregates, n = 0
   // fused3_kernel (the same ring with specialised pair / sum waves, two per SIMD) for the triple kind
   // with n >= 1 and m >= 2
-  bool v1 = false, v3 = false;
+  // nb_ring_kernel for the NB kind (no matrix product at all: sums, squares, counter increments)
+  bool v1 = false, v3 = false, vnb = false;
   auto fused_fits = [&]() {
     const int pref = ctx->fused_pref;
+    vnb = a->kind == COFACTOR_NB && (pref == 0 || pref == 4) && nbring_applicable(a->L, mask != nullptr, ctx->lds_max);
+    if (vnb) { v1 = v3 = false; return true; }
     // measured (tests/tools/onepass_compare.py, 5e7 rows): fused3 wins from 8 key columns on (10_10: 1.78 vs
     // 1.83 ms, 2_10: 1.25 vs 1.58), fused_kernel below (10_4: 1.06 vs 1.18); COFACTOR_FUSED=3 pins it
     const bool ok3 = (pref == 3 || (pref == 0 && a->m >= 8)) &&
@@ -726,7 +729,7 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       HIP_TRY(hipEventCreate(&e1));
       ctx->fused_ev.emplace_back(e0, e1);
     }
-    const int grid = v3 ? fused2_grid(ctx->cus, ctx->gram_grid, main_rows, 1)
+    const int grid = (v3 || vnb) ? fused2_grid(ctx->cus, ctx->gram_grid, main_rows, 1)
                    : v1 ? fused_grid(a->L, ctx->cus, ctx->gram_grid, main_rows)
                         : fused2_grid(ctx->cus, ctx->gram_grid, main_rows,
                                       fused2_wgs_per_cu(a->L, mask != nullptr, ctx->lds_max));
@@ -748,8 +751,11 @@ cofactor_status update_device_impl(cofactor_agg *a, const NumCols &num, const Ca
       skip = ctx->skip;
       HIP_TRY(hipMemsetAsync(skip, 0, sizeof(unsigned), st));
     }
-    ctx->last_fused = v3 ? "fused3_kernel" : (v1 ? "fused_kernel" : "fused2_kernel");
-    if (v3)
+    ctx->last_fused = vnb ? "nb_ring_kernel" : v3 ? "fused3_kernel" : (v1 ? "fused_kernel" : "fused2_kernel");
+    if (vnb)
+      HIP_TRY(launch_nbring(num, cat, main_rows, a->L, a->D, grid, ctx->lds_max, ctx->partials, skip, a->d_acc, st, e0, e1,
+                            mask, a->d_kept));
+    else if (v3)
       HIP_TRY(launch_fused3(num, cat, main_rows, a->L, a->D, grid, ctx->lds_max, ctx->partials, ctx->pair_slabs,
                             skip, a->d_acc, st, e0, e1, mask, a->d_kept));
     else if (v1)

@@ -290,6 +290,13 @@ hipError_t launch_fused3(const NumCols &num, const CatCols &cat, uint64_t rows, 
                          unsigned *skip, double *acc, hipStream_t stream, hipEvent_t ev0 = nullptr,
                          hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr,
                          unsigned long long *kept = nullptr);
+// ---- nbring.hip: sum_to_nb_agg in one pass on the ring without any matrix product (NB kind, m >= 1,
+// count tables + dictionaries next to the ring in LDS).  Skip list in FUSED2_SKIP_UNIT rows. ------------
+bool nbring_applicable(const CatLayout &L, bool masked, size_t lds_limit);
+hipError_t launch_nbring(const NumCols &num, const CatCols &cat, uint64_t rows, const CatLayout &L, const CatDevice &D,
+                         int grid, size_t lds_limit, double *partials, unsigned *skip, double *acc, hipStream_t stream,
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const uint8_t *mask = nullptr,
+                         unsigned long long *kept = nullptr);
 // D.p[cell] += sum over the workgroups' slabs (fused2.hip)
 hipError_t launch_pairs_fold2(const unsigned *slabs, int nwg, int n_p, unsigned long long *p, hipStream_t stream);
 hipError_t launch_gather_units(const NumCols &num, const CatCols &cat, int n, int m, int unit, const unsigned *list,

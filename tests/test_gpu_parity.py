@@ -652,13 +652,14 @@ def test_table_seam_alignment_and_roundtrip(ctx, n, m, nb, keys):
     agg.close()
 
 
-@pytest.mark.parametrize("pref", ["1", "2", "3"])
+@pytest.mark.parametrize("pref", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("n,m,nb,keys", [(10, 10, False, 16), (3, 2, False, 7), (0, 3, False, 16), (5, 1, False, 3),
                                           (20, 4, False, 9), (12, 7, False, 16), (16, 6, False, 12), (4, 3, True, 16),
                                           (0, 2, True, 5), (20, 10, True, 16), (7, 9, False, 2)])
 def test_both_one_pass_kernels_exact(monkeypatch, pref, n, m, nb, keys):
     """COFACTOR_FUSED=1 pins fused_kernel (three teams), =2 fused2_kernel (LDS-DMA ring, one-hot
-    MFMAs); shapes a kernel does not take go through the two-kernel path.  Integer-valued table,
+    MFMAs), =3 fused3_kernel (specialised waves), =4 nb_ring_kernel (NB kind only); shapes a kernel
+    does not take go through the others / the two-kernel path.  Integer-valued table,
     ragged row count, keys below zero (hash probe instead of the byte table) in every other column,
     plain and filtered updates, then a second update in optimistic mode that brings a new key:
     every count and sum must equal the oracle's exactly."""
@@ -792,3 +793,37 @@ def test_code_cache_route_without_a_dictionary_pass_meets_new_keys(ctx, n, m, k1
     agg.update_device(dn, dc)
     assert blob_to_dict(agg.finalize()) == blob_to_dict(orc.State(orc.FAITHFUL).update(num, cat).finalize())
     agg.close()
+
+
+@pytest.mark.parametrize("n,m,keys", [(10, 10, 16), (3, 2, 300), (0, 4, 1000), (20, 1, 40), (7, 20, 9)])
+def test_nb_ring_kernel_exact_at_any_cardinality(n, m, keys):
+    """nb_ring_kernel (default for sum_to_nb_agg): one row per lane, counts by LDS atomics, any
+    cardinality whose tables fit LDS — 16-bit code tables, keys below zero through the hash probe,
+    row filter, a second batch in optimistic mode with a new key.  Exact against the oracle."""
+    import torch
+    c2 = cofactor_hip.Context(0)
+    rng = np.random.default_rng(4000 + 11 * n + m)
+    rows = 150_000 + 41
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [(rng.integers(0, keys, rows) - (keys // 3 if c % 2 else 0)).astype(np.int32) for c in range(m)]
+    mask = (rng.random(rows) < 0.7).astype(np.uint8)
+    dn = [torch.from_numpy(c).cuda() for c in num]
+    dc = [torch.from_numpy(c).cuda() for c in cat]
+    dm = torch.from_numpy(mask).cuda()
+    torch.cuda.synchronize()
+    for use_mask in (False, True):
+        agg = c2.aggregate(n, m, cofactor_hip.NB)
+        sel = mask.astype(bool) if use_mask else np.ones(rows, dtype=bool)
+        (agg.update_device_masked(dn, dc, dm) if use_mask else agg.update_device(dn, dc))
+        want = orc.State(orc.WIDE).update([c[sel] for c in num], [c[sel] for c in cat], nb=True)
+        assert blob_to_dict(agg.finalize()) == blob_to_dict(want.finalize()), use_mask
+        cat2 = [c.copy() for c in cat]
+        cat2[0][70_000:70_005] = 123456                       # a key no dictionary holds yet
+        dc2 = [torch.from_numpy(c).cuda() for c in cat2]
+        torch.cuda.synchronize()
+        (agg.update_device_masked(dn, dc2, dm) if use_mask else agg.update_device(dn, dc2))
+        want.update([c[sel] for c in num], [c[sel] for c in cat2], nb=True)
+        assert blob_to_dict(agg.finalize()) == blob_to_dict(want.finalize()), ("second", use_mask)
+        c2.synchronize()
+        agg.close()
+    c2.close()
