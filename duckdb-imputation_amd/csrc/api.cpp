@@ -1292,7 +1292,8 @@ cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   ctx->allow_binned = env_long("COFACTOR_NO_BINNED", 0) == 0;
   ctx->stage_split = env_long("COFACTOR_STAGE_SPLIT", 0) != 0;
   ctx->stage_rows_max = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
-  HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)ctx->gram_grid * GRAM_ACC_LEN));
+  // (gram_narrow_kernel runs 16 workgroups per CU: room for that many images)
+  HIP_TRY(hipMalloc((void **)&ctx->partials, sizeof(double) * (size_t)std::max(ctx->gram_grid, 16 * ctx->cus) * GRAM_ACC_LEN));
   *out = ctx.release();
   return COFACTOR_OK;
 }

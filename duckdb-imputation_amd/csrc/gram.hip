@@ -665,6 +665,78 @@ static hipError_t launch_ring_n(const NumCols &cols, uint64_t nfull, int grid, s
   return hipGetLastError();
 }
 
+// ---- gram_narrow_kernel<N>, N = 1, 2: no tile pipeline, no MFMA ------------------------------------------
+// One or two columns are 4-8 bytes per row: gram_kernel's per-tile work (park, barrier, one MFMA per
+// row group) bounds it at 2.6 / 4.8 TB/s.  The whole triple of such a table is 2 / 5 numbers, so this
+// is the plain streaming reduction in the shape the calibration found fastest (one contiguous range
+// per workgroup, 16 workgroups per CU, four 16-byte non-temporal loads in flight per lane), with the
+// same arithmetic as everywhere: fp32 products, fp32 chains of <= 64 terms, folded into fp64.
+template <int N>
+__global__ __launch_bounds__(256) void gram_narrow_kernel(NumCols cols, uint64_t n4, double *__restrict__ partials) {
+  constexpr int NQ = N == 1 ? 1 : 3;                        // products: x0 x0 | x0 x0, x0 x1, x1 x1
+  const f32x4 *c0 = reinterpret_cast<const f32x4 *>(cols.p[0]);
+  const f32x4 *c1 = reinterpret_cast<const f32x4 *>(cols.p[N - 1]);
+  const uint64_t per = (n4 / gridDim.x) / 1024 * 1024;
+  uint64_t i = (uint64_t)blockIdx.x * per + threadIdx.x;
+  const uint64_t end = (uint64_t)blockIdx.x * per + per;
+  f32x4 fl[N], fq[NQ];
+  double dl[N], dq[NQ];
+#pragma unroll
+  for (int k = 0; k < N; k++) { fl[k] = f32x4{0, 0, 0, 0}; dl[k] = 0; }
+#pragma unroll
+  for (int k = 0; k < NQ; k++) { fq[k] = f32x4{0, 0, 0, 0}; dq[k] = 0; }
+  int since = 0;
+  for (; i < end; i += 1024) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      a[u] = __builtin_nontemporal_load(c0 + i + 256 * u);
+      if (N == 2) b[u] = __builtin_nontemporal_load(c1 + i + 256 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      fl[0] += a[u];
+      fq[0] += a[u] * a[u];
+      if (N == 2) { fl[N - 1] += b[u]; fq[1] += a[u] * b[u]; fq[NQ - 1] += b[u] * b[u]; }
+    }
+    if (++since == 16) {                                    // 64 terms per fp32 chain
+#pragma unroll
+      for (int k = 0; k < N; k++) { dl[k] += (double)((fl[k][0] + fl[k][1]) + (fl[k][2] + fl[k][3])); fl[k] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+      for (int k = 0; k < NQ; k++) { dq[k] += (double)((fq[k][0] + fq[k][1]) + (fq[k][2] + fq[k][3])); fq[k] = f32x4{0, 0, 0, 0}; }
+      since = 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) dl[k] += (double)((fl[k][0] + fl[k][1]) + (fl[k][2] + fl[k][3]));
+#pragma unroll
+  for (int k = 0; k < NQ; k++) dq[k] += (double)((fq[k][0] + fq[k][1]) + (fq[k][2] + fq[k][3]));
+  // workgroup sums in a fixed order: lanes by shuffles, waves through LDS
+  __shared__ double red[4][N + NQ];
+  double v[N + NQ];
+#pragma unroll
+  for (int k = 0; k < N; k++) v[k] = dl[k];
+#pragma unroll
+  for (int k = 0; k < NQ; k++) v[N + k] = dq[k];
+#pragma unroll
+  for (int k = 0; k < N + NQ; k++) {
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v[k];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < GRAM_ACC_LEN; idx += 256) partials[(uint64_t)idx * gridDim.x + blockIdx.x] = 0.0;
+  __syncthreads();
+  if (threadIdx.x < N + NQ) {
+    const int k = threadIdx.x;
+    const double t = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    int pos;
+    if (k < N) pos = gram_lin_pos(k, N);
+    else if (N == 1) pos = gram_quad_pos(0, 0, 1);
+    else pos = k - N == 0 ? gram_quad_pos(0, 0, 2) : (k - N == 1 ? gram_quad_pos(0, 1, 2) : gram_quad_pos(1, 1, 2));
+    partials[(uint64_t)pos * gridDim.x + blockIdx.x] = t;
+  }
+}
+
 // shape of the DMA kernel for n columns: waves per workgroup, ring depth, workgroups per CU (160 KB
 // of LDS per CU)
 static void gram_dma_shape(int n, int &waves, int &ring, int &wgs_per_cu, size_t &lds) {
@@ -828,6 +900,30 @@ hipError_t launch_gram(const NumCols &cols, int n, uint64_t rows, int grid, doub
   // (measured equal to gram_kernel, 13.4 vs 13.5 ms per 1e9 rows at n = 20: off by default)
   // gram_ring_kernel (dedicated loader waves): COFACTOR_GRAM_RING=0 switches it off, =1 forces it for
   // every n; by default it takes the column counts it was measured faster for (g_ring_min_n and up)
+  // one or two columns: the plain streaming reduction (gram_narrow_kernel); COFACTOR_GRAM_NARROW=0 switches it off
+  static const int narrow_env = [] { const char *v = getenv("COFACTOR_GRAM_NARROW"); return v ? atoi(v) : 1; }();
+  if (narrow_env && n <= 2 && !mask && rrows >= ((uint64_t)1 << 22)) {
+    bool aligned = true;
+    for (int k = 0; k < n; k++) aligned = aligned && ((reinterpret_cast<uintptr_t>(rest.p[k]) & 15) == 0);
+    if (aligned) {
+      static const int cus = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+      const int ngrid = 16 * cus;                           // (the context's partials hold max(gram grid, 16 x CUs) images)
+      const uint64_t n4 = rrows / 4, per = (n4 / ngrid) / 1024 * 1024;
+      const uint64_t done = per * (uint64_t)ngrid * 4;
+      if (per > 0) {
+        if (n == 1) hipLaunchKernelGGL(gram_narrow_kernel<1>, dim3(ngrid), dim3(256), 0, stream, rest, n4, partials);
+        else hipLaunchKernelGGL(gram_narrow_kernel<2>, dim3(ngrid), dim3(256), 0, stream, rest, n4, partials);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (done == rrows) {
+          if (ev1 && (e = hipEventRecord(ev1, stream)) != hipSuccess) return e;
+          return launch_gram_fold(partials, ngrid, acc, stream);
+        }
+        if ((e = launch_gram_fold(partials, ngrid, acc, stream)) != hipSuccess) return e;
+        for (int k = 0; k < n; k++) rest.p[k] += done;
+        rrows -= done;
+      }
+    }
+  }
   static const int ring_env = [] { const char *v = getenv("COFACTOR_GRAM_RING"); return v ? atoi(v) : -1; }();
   static const int dma_env_v = [] { const char *v = getenv("COFACTOR_GRAM_DMA"); return v ? atoi(v) : 0; }();
   const bool want_ring = ring_env == 1 || (ring_env != 0 && !dma_env_v && n >= GRAM_RING_MIN_N);
