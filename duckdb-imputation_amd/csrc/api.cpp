@@ -1289,6 +1289,7 @@ cofactor_status cofactor_ctx_create(int device, cofactor_ctx **out) {
   ctx->allow_optimistic = env_long("COFACTOR_NO_OPTIMISTIC", 0) == 0;
   ctx->fused_pref = (int)env_long("COFACTOR_FUSED", 0);
   ctx->no_sub = env_long("COFACTOR_NO_SUB", 0) != 0;
+  ctx->groups_seg = (int)env_long("COFACTOR_GROUPS_SEG", 0);
   ctx->allow_binned = env_long("COFACTOR_NO_BINNED", 0) == 0;
   ctx->stage_split = env_long("COFACTOR_STAGE_SPLIT", 0) != 0;
   ctx->stage_rows_max = (uint64_t)std::max(512L, env_long("COFACTOR_STAGE_ROWS", 1 << 18));
@@ -1308,6 +1309,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->skip);
   (void)hipFree(ctx->ring_red);
   (void)hipFree(ctx->ring_scratch);
+  (void)hipFree(ctx->seg_scratch);
   (void)hipFree(ctx->code_cache);
   (void)hipFree(ctx->pair_tmp);
   (void)hipFree(ctx->fin_dev);

@@ -26,6 +26,14 @@ hipError_t launch_max_i32(const int32_t *v, uint64_t rows, int *out, hipStream_t
 hipError_t launch_groups_accumulate(const int32_t *gid, const NumCols &num, const CatCols &cat, uint64_t rows,
                                     const CatLayout &L, const CatDevice &D, const CatLayout &Lg, const CatDevice &Dg,
                                     int is_key, double *tab, long long dtot, int grid, hipStream_t stream);
+// segmented path (groupseg.hip): numeric-only triples; rows <= 2^27 per call; scratch of groups_seg_scratch_bytes.
+// miss: device word set when a row's group is unknown; phase 0: the whole sequence, 2: the counting
+// pass only, 1: the rest after a phase-2 call on the same arguments.
+int groups_seg_record_floats(int n);
+size_t groups_seg_scratch_bytes(int n, uint64_t rows, long long groups, int cus);
+hipError_t launch_groups_segmented(const int32_t *gid, const NumCols &num, int n, uint64_t rows, const CatLayout &Lg,
+                                   const CatDevice &Dg, int is_key, long long groups, double *tab, long long dtot,
+                                   void *scratch, int cus, int32_t *miss, int phase, hipStream_t stream);
 hipError_t launch_groups_relayout(const CatLayout &Lo, const CatLayout &Ln, const double *to, double *tn, long long dto,
                                   long long dtn, long long groups, hipStream_t stream);
 hipError_t launch_groups_combine(double *tab, long long dtot, long long dst, long long src, hipStream_t stream);

@@ -550,6 +550,43 @@ cofactor_status cofactor_groups_update_device(cofactor_groups *g, const int32_t 
   CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   hipStream_t st = ctx->stream;
+  // wide numeric triples with many rows per group take the segmented path (groupseg.hip)
+  constexpr uint64_t SEG_MAX_ROWS = 1ull << 27;
+  const bool seg_shape = g->m == 0 && g->kind == 0 && g->n >= 1;
+  auto seg_wanted = [&](long long groups) {
+    return seg_shape && groups > 0 && groups < (1ll << 27) && ctx->groups_seg != 2 &&
+           (ctx->groups_seg == 1 || (g->n >= 2 && rows >= (1ull << 18) && rows >= 32ull * (uint64_t)groups));
+  };
+  auto seg_scratch = [&](uint64_t step, long long groups) -> cofactor_status {
+    const size_t need = groups_seg_scratch_bytes(g->n, step, groups, ctx->cus);
+    if (need > ctx->seg_scratch_bytes) {
+      HIP_TRY(hipStreamSynchronize(st));
+      (void)hipFree(ctx->seg_scratch);
+      ctx->seg_scratch = nullptr;
+      ctx->seg_scratch_bytes = 0;
+      HIP_TRY(hipMalloc(&ctx->seg_scratch, need + need / 8));
+      ctx->seg_scratch_bytes = need + need / 8;
+    }
+    return COFACTOR_OK;
+  };
+  // 0. key-typed groups that are all known already (every batch but the first few): the segmented
+  //    path's counting pass probes the dictionary anyway, so it doubles as the check and the insert
+  //    pass is skipped
+  if (g->is_key && rows <= SEG_MAX_ROWS && seg_wanted(g->groups)) {
+    cofactor_status s = seg_scratch(rows, g->groups);
+    if (s != COFACTOR_OK) return s;
+    HIP_TRY(hipMemsetAsync(g->Dg.flags + 2, 0, sizeof(int32_t), st));
+    HIP_TRY(launch_groups_segmented(d_gid, num, g->n, rows, g->Lg, g->Dg, 1, g->groups, g->tab, g->dtot, ctx->seg_scratch,
+                                    ctx->cus, g->Dg.flags + 2, 2, st));
+    int32_t miss = 0;
+    HIP_TRY(hipMemcpyAsync(&miss, g->Dg.flags + 2, sizeof(miss), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!miss) {
+      HIP_TRY(launch_groups_segmented(d_gid, num, g->n, rows, g->Lg, g->Dg, 1, g->groups, g->tab, g->dtot, ctx->seg_scratch,
+                                      ctx->cus, g->Dg.flags + 2, 1, st));
+      return COFACTOR_OK;
+    }
+  }
   g->dict_dirty = true;
   // 1. keys of the batch into the dictionaries (grown and re-run while one of them runs full)
   for (int attempt = 0;; attempt++) {
@@ -609,7 +646,20 @@ cofactor_status cofactor_groups_update_device(cofactor_groups *g, const int32_t 
     g->L = Ln;
   }
   g->groups = groups;
-  // 3. one launch for the whole batch
+  // 3. wide numeric triples with many rows per group: regroup the rows, then one matrix-core pass per group
+  //    (groupseg.hip); everything else: one launch, one atomic per cell per row
+  if (seg_wanted(groups)) {
+    const uint64_t step = std::min<uint64_t>(rows, SEG_MAX_ROWS);
+    cofactor_status s = seg_scratch(step, groups);
+    if (s != COFACTOR_OK) return s;
+    for (uint64_t r0 = 0; r0 < rows; r0 += step) {
+      NumCols part{};
+      for (int k = 0; k < g->n; k++) part.p[k] = num.p[k] + r0;
+      HIP_TRY(launch_groups_segmented(d_gid + r0, part, g->n, std::min<uint64_t>(step, rows - r0), g->Lg, g->Dg, g->is_key,
+                                      groups, g->tab, g->dtot, ctx->seg_scratch, ctx->cus, g->Dg.flags + 1, 0, st));
+    }
+    return COFACTOR_OK;
+  }
   HIP_TRY(launch_groups_accumulate(d_gid, num, cat, rows, g->L, g->D, g->Lg, g->Dg, g->is_key, g->tab, g->dtot,
                                    ctx->cus * 8, st));
   return COFACTOR_OK;

@@ -54,6 +54,9 @@ struct cofactor_ctx {
   size_t skip_bytes = 0;
   size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
   double *ring_red = nullptr;   // 256 doubles: reduced dense children of a vector of triples (sum_triple)
+  void *seg_scratch = nullptr;  // segmented GROUP BY (groupseg.hip): codes, offsets, regrouped records (grown on demand)
+  size_t seg_scratch_bytes = 0;
+  int groups_seg = 0;           // COFACTOR_GROUPS_SEG=1: segmented path whenever the shape allows, =2: never; default by size
   void *ring_scratch = nullptr; // multiply_triple: sub-list lengths / offsets / scan temporaries (grown on demand)
   size_t ring_scratch_bytes = 0;
   // multi-pass generic path: 16-bit key codes of the batch ([column][stride]) and the u32 cells of a

@@ -190,6 +190,91 @@ def test_group_by_state_pool_equals_per_group_oracle(ctx, n, m, nb, is_key):
     grp.close()
 
 
+@pytest.mark.parametrize("n,is_key", [(1, True), (3, False), (7, True), (12, False), (15, True), (16, False), (20, True)])
+def test_segmented_group_by_equals_per_group_oracle(n, is_key, monkeypatch):
+    """The regroup-then-matrix-core path of wide numeric triples (groupseg.hip), forced on: ragged
+    groups (empty ones, one of several work units, one of a single row), a row count that is no
+    multiple of anything, two batches (new groups in the second), every group against the oracle."""
+    monkeypatch.setenv("COFACTOR_GROUPS_SEG", "1")
+    c = cofactor_hip.Context(0)
+    try:
+        rng = np.random.default_rng(900 + n)
+        G, rows = 97, 60_001
+        keys = (rng.permutation(10_000)[:G] * 3 - 7_000).astype(np.int32) if is_key else np.arange(G, dtype=np.int32)
+        slot = rng.integers(0, G, rows).astype(np.int32)
+        slot[slot % 5 == 3] = 11                       # a group of ~12 000 rows: several units; groups = 3 mod 5 stay empty
+        slot[:rows // 2][slot[:rows // 2] > 60] = 2    # groups above 60 only appear in the second batch
+        slot[-1] = 63                                  # (3 mod 5) a group of exactly one row
+        num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+        gid = keys[slot]
+        grp = ring.Groups(c, n, 0, cofactor_hip.TRIPLE, is_key=is_key)
+        h = rows // 2
+        dev = _cuda([gid[:h]]) + _cuda([x[:h] for x in num])
+        grp.update_device(dev[0], dev[1:], [])
+        grp.update_host(gid[h:], [x[h:] for x in num], [])
+        grp.update_device(dev[0], dev[1:], [])         # every group known: the counting pass doubles as the dictionary check
+        present = np.unique(slot)
+        assert grp.count() == (len(present) if is_key else int(slot.max()) + 1)
+        want = orc.grouped_update([np.concatenate([x, x[:h]]) for x in num], [], np.concatenate([slot, slot[:h]]), G, nb=False)
+        for s_ in present:
+            assert blob_to_dict(grp.finalize(int(keys[s_]))) == blob_to_dict(want[s_].finalize()), s_
+        grp.close()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("is_key", [True, False])
+def test_segmented_group_by_with_more_groups_than_the_lds_histogram_holds(is_key, monkeypatch):
+    """40 000 groups: counters and cursors in global memory (the *_atomic kernels of groupseg.hip)."""
+    monkeypatch.setenv("COFACTOR_GROUPS_SEG", "1")
+    c = cofactor_hip.Context(0)
+    try:
+        rng = np.random.default_rng(77)
+        n, G, rows = 5, 40_000, 300_007
+        keys = (rng.permutation(1_000_000)[:G] - 500_000).astype(np.int32) if is_key else np.arange(G, dtype=np.int32)
+        slot = rng.integers(0, G, rows).astype(np.int32)
+        slot[::3] = 39_999
+        num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+        gid = keys[slot]
+        grp = ring.Groups(c, n, 0, cofactor_hip.TRIPLE, is_key=is_key)
+        dev = _cuda([gid]) + _cuda(num)
+        grp.update_device(dev[0], dev[1:], [])
+        grp.update_device(dev[0], dev[1:], [])
+        want = orc.grouped_update([np.concatenate([x, x]) for x in num], [], np.concatenate([slot, slot]), G, nb=False)
+        present = np.unique(slot)
+        for s_ in list(present[::400]) + [39_999]:
+            assert blob_to_dict(grp.finalize(int(keys[s_]))) == blob_to_dict(want[s_].finalize()), s_
+        grp.close()
+    finally:
+        c.close()
+
+
+def test_segmented_group_by_matches_the_atomic_path_on_real_values():
+    """Non-integer values: the segmented path (fp32 chains of 64 rows folded into fp64, gram.hip's rule)
+    against the per-row path (float products summed in fp64) within 1e-6 relative."""
+    import os
+    import torch
+    from cofactor_hip import synth
+    n, G, rows = 20, 1000, 1 << 20
+    num, _ = synth.table(torch, 5, n, 0, 0, rows, "cuda", keys=4)
+    gid = synth.integers(torch, 5, 300, 0, rows, G, "cuda")
+    out = []
+    for knob in ("1", "2"):
+        os.environ["COFACTOR_GROUPS_SEG"] = knob
+        try:
+            c = cofactor_hip.Context(0)
+        finally:
+            del os.environ["COFACTOR_GROUPS_SEG"]
+        grp = ring.Groups(c, n, 0, cofactor_hip.TRIPLE, is_key=False)
+        grp.update_device(gid, num, [])
+        out.append([np.asarray(grp.finalize(g)) for g in (0, 1, 500, 999)])
+        grp.close()
+        c.close()
+    for a, b in zip(*out):
+        assert a.shape == b.shape and a.size >= 231
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
 def _join_tables(G, per, seed):
     rng = np.random.default_rng(seed)
     rows = G * per

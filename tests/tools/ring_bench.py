@@ -48,7 +48,8 @@ def main():
         del tv, num, cat
         torch.cuda.empty_cache()
     # GROUP BY pool: 2_2, 1e5 groups, 2e7 rows; and 20_0 with 1e4 groups
-    for n, m, G, rows in ((2, 2, 100_000, 20_000_000), (20, 0, 10_000, 20_000_000)):
+    for n, m, G, rows in ((2, 2, 100_000, 20_000_000), (20, 0, 10_000, 20_000_000), (20, 0, 10_000, 100_000_000),
+                          (8, 0, 10_000, 100_000_000)):
         num, cat = synth.table(torch, 42, n, m, 0, rows, dev, keys=4)
         gid = synth.integers(torch, 42, 300, 0, rows, G, dev)
         grp = ring.Groups(ctx, n, m, is_key=True)
@@ -58,7 +59,7 @@ def main():
         ctx.synchronize()
         first = time.perf_counter() - t0
         dt = timed(lambda: grp.update_device(gid, num, cat), ctx, reps=3)
-        out["groups_%d_%d_G%d" % (n, m, G)] = {"rows": rows, "rows_per_s": rows / dt, "first_batch_s": first}
+        out["groups_%d_%d_G%d_R%.0e" % (n, m, G, rows)] = {"rows": rows, "rows_per_s": rows / dt, "first_batch_s": first}
         if (n, m) == (2, 2):
             A, ka = grp.to_tvec(dev)
             sel = np.arange(G)
@@ -77,6 +78,8 @@ def main():
             out["multiply_2_2x2_2_big"] = {"pairs": len(big), "pairs_per_s": len(big) / ((time.perf_counter() - t0) / 3)}
             del prod
         grp.close()
+        del num, cat, gid
+        torch.cuda.empty_cache()
     print(json.dumps(out))
     ctx.close()
 
