@@ -237,6 +237,10 @@ def multiply(ctx, a, b, a_sel=None, b_sel=None, rows=None):
             keep.append(arr)
             return arr.ctypes.data
         import torch
+        if hasattr(s, "data_ptr"):                  # already a device tensor of 32-bit indices
+            assert s.dtype == torch.int32 and s.is_contiguous()
+            keep.append(s)
+            return s.data_ptr()
         t = torch.as_tensor(np.ascontiguousarray(s, dtype=np.int64), device=dev).to(torch.int32)
         keep.append(t)
         torch.cuda.synchronize()

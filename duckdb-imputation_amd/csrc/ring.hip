@@ -334,115 +334,6 @@ __global__ __launch_bounds__(256) void tvec_keys_lds_kernel(cofactor_tvec v, Cat
   }
 }
 
-// ---- multiply_triple -----------------------------------------------------------------------------
-struct MulShape { int nA, mA, nB, mB, kind; };
-
-// N, lin, quad of the product and their list entries: one thread per element (regular shape)
-__global__ __launch_bounds__(256) void mul_dense_kernel(cofactor_tvec a, const uint32_t *__restrict__ asel, cofactor_tvec b,
-                                                        const uint32_t *__restrict__ bsel, uint64_t rows, cofactor_tvec o) {
-  const int nA = a.n, nB = b.n, nR = nA + nB, kind = a.kind;
-  const int TR = kind ? nR : tri_i(nR);
-  const int D = 1 + nR + TR;
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < rows * D; w += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t i = w / D;
-    const int e = (int)(w % D);
-    const uint64_t ia = asel ? asel[i] : i, ib = bsel ? bsel[i] : i;
-    const float Na = (float)a.N[ia], Nb = (float)b.N[ib];
-    const float *la = a.lin + a.lin_e[2 * ia], *lb = b.lin + b.lin_e[2 * ib];
-    const float *qa = a.quad + a.quad_e[2 * ia], *qb = b.quad + b.quad_e[2 * ib];
-    if (e == 0) {
-      o.N[i] = a.N[ia] * b.N[ib];                    // int32 product (mul.cpp:46-49)
-      o.lin_e[2 * i] = i * nR; o.lin_e[2 * i + 1] = nR;
-      o.quad_e[2 * i] = i * TR; o.quad_e[2 * i + 1] = TR;
-      // a list family without sub-lists (no key columns / no numeric columns): empty outer lists
-      const int mR = a.m + b.m;
-      if (mR == 0 && o.lc_outer) { o.lc_outer[2 * i] = 0; o.lc_outer[2 * i + 1] = 0; }
-      if (!kind && nR * mR == 0 && o.nc_outer) { o.nc_outer[2 * i] = 0; o.nc_outer[2 * i + 1] = 0; }
-      if (!kind && mR == 0 && o.cc_outer) { o.cc_outer[2 * i] = 0; o.cc_outer[2 * i + 1] = 0; }
-    } else if (e <= nR) {                            // lin = [N_B lin_A | N_A lin_B] (mul.cpp:97-107)
-      const int k = e - 1;
-      o.lin[i * nR + k] = k < nA ? la[k] * Nb : lb[k - nA] * Na;
-    } else {
-      int q = e - 1 - nR;
-      float val;
-      if (kind) val = q < nA ? qa[q] * Nb : qb[q - nA] * Na;          // mul_nb.cpp:246-262
-      else {                                         // upper triangle of [[N_B Q_A, lin_A (x) lin_B], [., N_A Q_B]]
-        int j = 0, r = q;
-        while (r >= nR - j) { r -= nR - j; j++; }
-        const int k = j + r;
-        if (k < nA) val = qa[pair_q(j, k, nA)] * Nb;
-        else if (j < nA) val = la[j] * lb[k - nA];
-        else val = qb[pair_q(j - nA, k - nA, nB)] * Na;
-      }
-      o.quad[i * TR + q] = val;
-    }
-  }
-}
-
-// Every output sub-list is one or two source sub-lists (mul.cpp:185-217, 377-446, 542-598):
-//   mode 0: its length -> len[] (then an exclusive scan gives the offsets)
-//   mode 1: entries, sub-list entry and (thread s == 0) the row's outer entry
-__global__ __launch_bounds__(256) void mul_lists_kernel(cofactor_tvec a, const uint32_t *__restrict__ asel, cofactor_tvec b,
-                                                        const uint32_t *__restrict__ bsel, uint64_t rows, int family,
-                                                        uint64_t *__restrict__ len, const uint64_t *__restrict__ offs,
-                                                        cofactor_tvec o, int mode) {
-  const int nA = a.n, mA = a.m, nB = b.n, mB = b.m, nR = nA + nB, mR = mA + mB;
-  const int per_row = family == 0 ? mR : (family == 1 ? nR * mR : tri_i(mR));
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < rows * per_row; w += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t i = w / per_row;
-    const int s = (int)(w % per_row);
-    const uint64_t ia = asel ? asel[i] : i, ib = bsel ? bsel[i] : i;
-    const float Na = (float)a.N[ia], Nb = (float)b.N[ib];
-    // source: up to two sub-lists (s1 x s2 = outer product when both are set), one scale factor
-    const uint64_t *e1 = nullptr, *e2 = nullptr;      // (offset, length) entries
-    const int32_t *k1 = nullptr, *k1b = nullptr, *k2 = nullptr;
-    const float *v1 = nullptr, *v2 = nullptr;
-    float scale = 1.f;
-    if (family == 0) {                               // lin_cat = [N_B lcat_A | N_A lcat_B]
-      if (s < mA) { e1 = a.lc_sub + 2 * (a.lc_outer[2 * ia] + s); k1 = a.lc_key; v1 = a.lc_val; scale = Nb; }
-      else { e1 = b.lc_sub + 2 * (b.lc_outer[2 * ib] + (s - mA)); k1 = b.lc_key; v1 = b.lc_val; scale = Na; }
-    } else if (family == 1) {                        // quad_num_cat, numeric-major over (A|B), key-minor over (A|B)
-      const int j = s / mR, c = s % mR;
-      if (j < nA && c < mA) { e1 = a.nc_sub + 2 * (a.nc_outer[2 * ia] + j * mA + c); k1 = a.nc_key; v1 = a.nc_val; scale = Nb; }
-      else if (j < nA) { e1 = b.lc_sub + 2 * (b.lc_outer[2 * ib] + (c - mA)); k1 = b.lc_key; v1 = b.lc_val; scale = a.lin[a.lin_e[2 * ia] + j]; }
-      else if (c < mA) { e1 = a.lc_sub + 2 * (a.lc_outer[2 * ia] + c); k1 = a.lc_key; v1 = a.lc_val; scale = b.lin[b.lin_e[2 * ib] + (j - nA)]; }
-      else { e1 = b.nc_sub + 2 * (b.nc_outer[2 * ib] + (j - nA) * mB + (c - mA)); k1 = b.nc_key; v1 = b.nc_val; scale = Na; }
-    } else {                                         // quad_cat over the joined key columns
-      int c1, c2;
-      pair_decode(s, mR, c1, c2);
-      if (c2 < mA) { e1 = a.cc_sub + 2 * (a.cc_outer[2 * ia] + pair_q(c1, c2, mA)); k1 = a.cc_key1; k1b = a.cc_key2; v1 = a.cc_val; scale = Nb; }
-      else if (c1 >= mA) { e1 = b.cc_sub + 2 * (b.cc_outer[2 * ib] + pair_q(c1 - mA, c2 - mA, mB)); k1 = b.cc_key1; k1b = b.cc_key2; v1 = b.cc_val; scale = Na; }
-      else {                                         // A x B: key-set outer product, count_A * count_B (mul.cpp:564-580)
-        e1 = a.lc_sub + 2 * (a.lc_outer[2 * ia] + c1); k1 = a.lc_key; v1 = a.lc_val;
-        e2 = b.lc_sub + 2 * (b.lc_outer[2 * ib] + (c2 - mA)); k2 = b.lc_key; v2 = b.lc_val;
-      }
-    }
-    const uint64_t l1 = e1[1], l2 = e2 ? e2[1] : 1;
-    if (mode == 0) { len[w] = l1 * l2; continue; }
-    const uint64_t off = offs[w];
-    uint64_t *sub = family == 0 ? o.lc_sub : (family == 1 ? o.nc_sub : o.cc_sub);
-    uint64_t *outer = family == 0 ? o.lc_outer : (family == 1 ? o.nc_outer : o.cc_outer);
-    sub[2 * w] = off; sub[2 * w + 1] = l1 * l2;
-    if (s == 0) { outer[2 * i] = w; outer[2 * i + 1] = (uint64_t)per_row; }
-    uint64_t t = off;
-    for (uint64_t x = 0; x < l1; x++) {
-      const uint64_t ea = e1[0] + x;
-      if (e2) {
-        for (uint64_t y = 0; y < l2; y++, t++) {
-          const uint64_t eb = e2[0] + y;
-          o.cc_key1[t] = k1[ea]; o.cc_key2[t] = k2[eb]; o.cc_val[t] = v1[ea] * v2[eb];
-        }
-      } else if (family == 2) {
-        o.cc_key1[t] = k1[ea]; o.cc_key2[t] = k1b[ea]; o.cc_val[t] = v1[ea] * scale; t++;
-      } else if (family == 1) {
-        o.nc_key[t] = k1[ea]; o.nc_val[t] = v1[ea] * scale; t++;
-      } else {
-        o.lc_key[t] = k1[ea]; o.lc_val[t] = v1[ea] * scale; t++;
-      }
-    }
-  }
-}
-
 // ---- GROUP BY state pool ---------------------------------------------------------------------------
 // Row g of tab (Dtot doubles): [N | lin(n) | quad(T) | cnt(n_cnt) | s(n_s) | p(n_p)], L's offsets.
 // A wave takes 64 consecutive rows: lane r stages row r (group, values, key codes) in LDS, then the
@@ -706,25 +597,6 @@ hipError_t launch_tvec_keys(const cofactor_tvec &v, const CatLayout &L, const Ca
   } else {
     hipLaunchKernelGGL(tvec_keys_kernel, dim3(grid_for(total)), dim3(256), 0, stream, v, L, D, pass);
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_mul_dense(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
-                            uint64_t rows, const cofactor_tvec &out, hipStream_t stream) {
-  if (rows == 0) return hipSuccess;
-  const int nR = a.n + b.n, TR = a.kind ? nR : tri_i(nR);
-  hipLaunchKernelGGL(mul_dense_kernel, dim3(grid_for(rows * (1 + nR + TR))), dim3(256), 0, stream, a, asel, b, bsel, rows, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_mul_lists(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
-                            uint64_t rows, int family, uint64_t *len, const uint64_t *offs, const cofactor_tvec &out,
-                            int mode, hipStream_t stream) {
-  const int mR = a.m + b.m, nR = a.n + b.n;
-  const int per_row = family == 0 ? mR : (family == 1 ? nR * mR : tri_i(mR));
-  if (rows == 0 || per_row == 0) return hipSuccess;
-  hipLaunchKernelGGL(mul_lists_kernel, dim3(grid_for(rows * per_row)), dim3(256), 0, stream, a, asel, b, bsel, rows,
-                     family, len, offs, out, mode);
   return hipGetLastError();
 }
 

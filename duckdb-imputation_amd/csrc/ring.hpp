@@ -11,12 +11,12 @@ hipError_t launch_tvec_dense(const cofactor_tvec &v, double *red, double *acc, u
                              hipStream_t stream);
 // pass 0: keys into the dictionaries; pass 1: values into the count / sum / pair tables
 hipError_t launch_tvec_keys(const cofactor_tvec &v, const CatLayout &L, const CatDevice &D, int pass, hipStream_t stream);
-hipError_t launch_mul_dense(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
-                            uint64_t rows, const cofactor_tvec &out, hipStream_t stream);
-// family 0 lin_cat, 1 quad_num_cat, 2 quad_cat; mode 0: sub-list lengths into len, mode 1: fill at offs
-hipError_t launch_mul_lists(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
-                            uint64_t rows, int family, uint64_t *len, const uint64_t *offs, const cofactor_tvec &out,
-                            int mode, hipStream_t stream);
+// multiply_triple (mulfill.hip): per-row totals of the three list families; the one-pass fill at the rows' places
+hipError_t launch_mul_pair_lens(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
+                                uint64_t rows, uint64_t *t0, uint64_t *t1, uint64_t *t2, hipStream_t stream);
+hipError_t launch_mul_fill(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
+                           uint64_t rows, const uint64_t *base0, const uint64_t *base1, const uint64_t *base2,
+                           const cofactor_tvec &out, int cus, hipStream_t stream);
 hipError_t ring_exclusive_scan(const uint64_t *len, uint64_t *offs, uint64_t items, void *temp, size_t *temp_bytes,
                                hipStream_t stream);
 

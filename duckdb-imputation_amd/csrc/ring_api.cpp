@@ -225,23 +225,26 @@ cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec 
   if (!tvec_dense_ok(a) || !tvec_lists_ok(a) || !tvec_dense_ok(b) || !tvec_lists_ok(b))
     return fail(COFACTOR_ERR_INVALID, "multiply: an input array is null");
   const int nR = a->n + b->n, mR = a->m + b->m, kind = a->kind;
-  const uint64_t per[3] = {(uint64_t)mR, kind ? 0 : (uint64_t)nR * mR, kind ? 0 : tri64(mR)};
+  const bool fam[3] = {mR > 0, !kind && nR * mR > 0, !kind && mR > 0};
   CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   hipStream_t st = ctx->stream;
-  // sub-list lengths, their exclusive scans and the scans' temporaries: carved from one context
-  // scratch block (no allocation per call), all three families enqueued before the ONE
-  // synchronisation that brings the three payload sizes back
-  uint64_t items[3], need[3] = {0, 0, 0};
-  size_t temp_bytes[3] = {0, 0, 0}, total_bytes = 0;
-  for (int f = 0; f < 3; f++) {
-    items[f] = rows * per[f];
-    if (items[f] > 0x7fffffffull) return fail(COFACTOR_ERR_UNSUPPORTED, "too many sub-lists for one call");
-    if (items[f] == 0) continue;
-    HIP_TRY(ring_exclusive_scan(nullptr, nullptr, items[f], nullptr, &temp_bytes[f], st));
-    total_bytes += items[f] * 16 + ((temp_bytes[f] + 255) & ~(size_t)255) + 512;
-  }
-  if (total_bytes > ctx->ring_scratch_bytes) {
+  if (rows > 0x7fffffffull) return fail(COFACTOR_ERR_UNSUPPORTED, "too many rows for one call");
+  // The plan of a call: per row the entries of its three list families (mulfill.hip) and their
+  // exclusive scans over the ROWS, in one context scratch block (no allocation per call).  A size
+  // query leaves its plan behind; the fill call that follows it with the same arguments takes it
+  // over instead of computing it again (the inputs must not change in between).
+  const uintptr_t key[8] = {(uintptr_t)a->N, (uintptr_t)a->lc_sub, (uintptr_t)b->N, (uintptr_t)b->lc_sub,
+                            (uintptr_t)d_a_sel, (uintptr_t)d_b_sel, (uintptr_t)rows,
+                            (uintptr_t)(a->n | (a->m << 8) | (b->n << 16) | (b->m << 24)) ^ ((uintptr_t)kind << 40)};
+  const bool reuse = out && ctx->mul_plan_valid && std::memcmp(key, ctx->mul_plan_key, sizeof(key)) == 0;
+  ctx->mul_plan_valid = false;
+  uint64_t need[3] = {0, 0, 0};
+  size_t temp_bytes = 0;
+  if (rows) HIP_TRY(ring_exclusive_scan(nullptr, nullptr, rows, nullptr, &temp_bytes, st));
+  const size_t col = (rows * 8 + 255) & ~(size_t)255;
+  const size_t total_bytes = 6 * col + ((temp_bytes + 255) & ~(size_t)255) + 512;
+  if (!reuse && total_bytes > ctx->ring_scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(st));               // kernels of earlier calls may still read the old block
     (void)hipFree(ctx->ring_scratch);
     ctx->ring_scratch = nullptr;
@@ -249,38 +252,39 @@ cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec 
     HIP_TRY(hipMalloc(&ctx->ring_scratch, total_bytes + total_bytes / 4));
     ctx->ring_scratch_bytes = total_bytes + total_bytes / 4;
   }
-  uint64_t *len[3] = {nullptr, nullptr, nullptr}, *offs[3] = {nullptr, nullptr, nullptr};
-  uint64_t tail[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-  cofactor_tvec none{};
-  {
-    char *cur = reinterpret_cast<char *>(ctx->ring_scratch);
-    auto take = [&](size_t bytes) { char *at = cur; cur += (bytes + 255) & ~(size_t)255; return at; };
+  char *blk = reinterpret_cast<char *>(ctx->ring_scratch);
+  uint64_t *tot[3], *base[3];
+  for (int f = 0; f < 3; f++) { tot[f] = reinterpret_cast<uint64_t *>(blk + f * col); base[f] = reinterpret_cast<uint64_t *>(blk + (3 + f) * col); }
+  void *temp = blk + 6 * col;
+  if (reuse) {
+    for (int f = 0; f < 3; f++) need[f] = ctx->mul_plan_need[f];
+  } else if (rows) {
+    uint64_t tail[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    HIP_TRY(launch_mul_pair_lens(*a, d_a_sel, *b, d_b_sel, rows, tot[0], tot[1], tot[2], st));
     for (int f = 0; f < 3; f++) {
-      if (items[f] == 0) continue;
-      len[f] = reinterpret_cast<uint64_t *>(take(items[f] * 8));
-      offs[f] = reinterpret_cast<uint64_t *>(take(items[f] * 8));
-      void *temp = take(temp_bytes[f]);
-      HIP_TRY(launch_mul_lists(*a, d_a_sel, *b, d_b_sel, rows, f, len[f], nullptr, none, 0, st));
-      HIP_TRY(ring_exclusive_scan(len[f], offs[f], items[f], temp, &temp_bytes[f], st));
-      HIP_TRY(hipMemcpyAsync(&tail[f][0], offs[f] + items[f] - 1, 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(&tail[f][1], len[f] + items[f] - 1, 8, hipMemcpyDeviceToHost, st));
+      if (!fam[f]) continue;
+      HIP_TRY(ring_exclusive_scan(tot[f], base[f], rows, temp, &temp_bytes, st));
+      HIP_TRY(hipMemcpyAsync(&tail[f][0], base[f] + rows - 1, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&tail[f][1], tot[f] + rows - 1, 8, hipMemcpyDeviceToHost, st));
     }
+    HIP_TRY(hipStreamSynchronize(st));               // the ONE synchronisation: the three payload sizes
+    for (int f = 0; f < 3; f++) need[f] = tail[f][0] + tail[f][1];
   }
-  HIP_TRY(hipStreamSynchronize(st));
-  for (int f = 0; f < 3; f++) need[f] = tail[f][0] + tail[f][1];
   if (lc_need) *lc_need = need[0];
   if (nc_need) *nc_need = need[1];
   if (cc_need) *cc_need = need[2];
-  if (!out) return COFACTOR_OK;
+  if (!out) {
+    std::memcpy(ctx->mul_plan_key, key, sizeof(key));
+    for (int f = 0; f < 3; f++) ctx->mul_plan_need[f] = need[f];
+    ctx->mul_plan_valid = rows > 0;
+    return COFACTOR_OK;
+  }
   out->count = rows; out->n = nR; out->m = mR; out->kind = kind;
   if (rows == 0) return COFACTOR_OK;
   if (out->lc_cap < need[0] || out->nc_cap < need[1] || out->cc_cap < need[2])
     return fail(COFACTOR_ERR_CAPACITY, "multiply: payload arrays too small");
   if (!tvec_dense_ok(out) || !tvec_lists_ok(out)) return fail(COFACTOR_ERR_INVALID, "multiply: an output array is null");
-  HIP_TRY(launch_mul_dense(*a, d_a_sel, *b, d_b_sel, rows, *out, st));
-  for (int f = 0; f < 3; f++)
-    if (items[f])
-      HIP_TRY(launch_mul_lists(*a, d_a_sel, *b, d_b_sel, rows, f, nullptr, offs[f], *out, 1, st));
+  HIP_TRY(launch_mul_fill(*a, d_a_sel, *b, d_b_sel, rows, base[0], base[1], base[2], *out, ctx->cus, st));
   // (asynchronous from here, like every device entry point: the scratch block stays the context's)
   return COFACTOR_OK;
 }

@@ -59,6 +59,10 @@ struct cofactor_ctx {
   int groups_seg = 0;           // COFACTOR_GROUPS_SEG=1: segmented path whenever the shape allows, =2: never; default by size
   void *ring_scratch = nullptr; // multiply_triple: sub-list lengths / offsets / scan temporaries (grown on demand)
   size_t ring_scratch_bytes = 0;
+  // multiply_triple: the plan a size query left in ring_scratch for the fill call that follows it
+  bool mul_plan_valid = false;
+  uintptr_t mul_plan_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t mul_plan_need[3] = {0, 0, 0};
   // multi-pass generic path: 16-bit key codes of the batch ([column][stride]) and the u32 cells of a
   // pair table too big for LDS
   unsigned short *code_cache = nullptr;

@@ -127,7 +127,7 @@ def test_sum_triple_of_lifted_rows_equals_the_fused_aggregate(ctx, n, m, nb):
 
 
 @pytest.mark.parametrize("shape", [((2, 2), (2, 2), False), ((3, 0), (0, 2), False), ((1, 3), (4, 1), False), ((0, 1), (0, 1), False),
-                                   ((2, 2), (3, 1), True)])
+                                   ((2, 2), (3, 1), True), ((3, 4), (4, 3), False), ((6, 5), (5, 6), False), ((2, 9), (1, 8), True)])
 def test_multiply_kernel_equals_oracle_on_grouped_triples(ctx, shape):
     """multiply_triple over a batch of 500 row pairs of GROUP BY triples (ragged key lists) with
     selection vectors on both sides, device and host entry points."""
