@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void tvec_keys_kernel(cofactor_tvec v, CatLayo
     s -= nm;
     {
       int c1, c2;
+      if (pair_is_sparse(L, s)) continue;             // (kept as a sorted list: tvec_sparse_fill_kernel)
       pair_decode(s, m, c1, c2);
       const uint64_t sub = v.cc_outer[2 * i] + s, off = v.cc_sub[2 * sub], len = v.cc_sub[2 * sub + 1];
       for (uint64_t e = off; e < off + len; e++) {
@@ -266,6 +267,7 @@ __device__ __forceinline__ bool tvec_child_to_lds(const cofactor_tvec &v, const 
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
+      if (KIND == 2 && len[u] && pair_is_sparse(L, sidx[u])) len[u] = 0;   // (kept as a sorted list)
       off[u] = len[u] ? sube[2 * sub[u]] : 0;
       len[u] = len[u] ? sube[2 * sub[u] + 1] : 0;
       maxlen = max(maxlen, len[u]);
@@ -583,6 +585,40 @@ hipError_t launch_tvec_dense(const cofactor_tvec &v, double *red, double *acc, u
                        T, red + 1 + v.n);
   }
   hipLaunchKernelGGL(tvec_dense_apply_kernel, dim3(1), dim3(256), 0, stream, red, v.n, v.kind, acc, kept);
+  return hipGetLastError();
+}
+
+// quad_cat entries of the column pairs a state keeps as sorted lists: counted per pair, then written
+// as (packed key pair, count) — in any order, sparse_merge_lists sorts and folds them
+__global__ __launch_bounds__(256) void tvec_sparse_kernel(cofactor_tvec v, CatLayout L, unsigned long long *__restrict__ counts,
+                                                          const unsigned long long *__restrict__ base,
+                                                          unsigned long long *__restrict__ keys,
+                                                          unsigned long long *__restrict__ cnt, int fill) {
+  const int per = tri_i(v.m);
+  const uint64_t total = v.count * (uint64_t)per;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = w / per;
+    const int q = (int)(w - i * per);
+    if (!pair_is_sparse(L, q)) continue;
+    const uint64_t sub = v.cc_outer[2 * i] + q, off = v.cc_sub[2 * sub], len = v.cc_sub[2 * sub + 1];
+    if (len == 0) continue;
+    const unsigned long long at = atomicAdd(&counts[q], (unsigned long long)len);
+    if (!fill) continue;
+    for (uint64_t e = 0; e < len; e++) {
+      const unsigned long long k = ((unsigned long long)((uint32_t)v.cc_key1[off + e] ^ 0x80000000u) << 32) |
+                                   (unsigned long long)((uint32_t)v.cc_key2[off + e] ^ 0x80000000u);   // = sparse_pack
+      keys[base[q] + at + e] = k;
+      cnt[base[q] + at + e] = (unsigned long long)(v.cc_val[off + e] + 0.5f);
+    }
+  }
+}
+
+hipError_t launch_tvec_sparse(const cofactor_tvec &v, const CatLayout &L, unsigned long long *counts,
+                              const unsigned long long *base, unsigned long long *keys, unsigned long long *cnt, int fill,
+                              hipStream_t stream) {
+  const uint64_t total = v.count * (uint64_t)tri_i(v.m);
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(tvec_sparse_kernel, dim3(grid_for(total)), dim3(256), 0, stream, v, L, counts, base, keys, cnt, fill);
   return hipGetLastError();
 }
 

@@ -12,6 +12,11 @@ hipError_t launch_tvec_dense(const cofactor_tvec &v, double *red, double *acc, u
 // pass 0: keys into the dictionaries; pass 1: values into the count / sum / pair tables
 hipError_t launch_tvec_keys(const cofactor_tvec &v, const CatLayout &L, const CatDevice &D, int pass, hipStream_t stream);
 // multiply_triple (mulfill.hip): per-row totals of the three list families; the one-pass fill at the rows' places
+// quad_cat entries of the pairs L keeps as sorted lists: fill == 0 counts them per pair (counts, zeroed by the
+// caller); fill == 1 writes them as (packed key pair, count) from base[pair] on (counts zeroed again: cursors)
+hipError_t launch_tvec_sparse(const cofactor_tvec &v, const CatLayout &L, unsigned long long *counts,
+                              const unsigned long long *base, unsigned long long *keys, unsigned long long *cnt, int fill,
+                              hipStream_t stream);
 hipError_t launch_mul_pair_lens(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
                                 uint64_t rows, uint64_t *t0, uint64_t *t1, uint64_t *t2, hipStream_t stream);
 hipError_t launch_mul_fill(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,

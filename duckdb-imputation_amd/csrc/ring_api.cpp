@@ -203,15 +203,44 @@ cofactor_status cofactor_agg_update_tvec_device(cofactor_agg *a, const cofactor_
   if (a->m > 0) {
     s = cat_dictionaries_with(a, [&]() { return launch_tvec_keys(*v, a->L, a->D, 0, st); });
     if (s != COFACTOR_OK) return s;
-    if (any_sparse_pair(a->L))                    // (before anything is added: the state stays consistent)
-      return fail(COFACTOR_ERR_UNSUPPORTED,
-                  "sum_triple into a state with sparse pair tables (very high cardinalities) is not implemented");
   }
   a->dev_dirty = true;
   HIP_TRY(launch_tvec_dense(*v, ctx->ring_red, a->d_acc, a->d_kept, ctx->gram_grid, st));
   if (a->m > 0) {
     HIP_TRY(launch_tvec_keys(*v, a->L, a->D, 1, st));
     a->cat_check_pending = true;
+  }
+  // column pairs the state keeps as sorted lists (sum.cpp:246-260 adds into a std::map): their
+  // quad_cat entries become one (packed keys, count) list per pair, merged into the pair's store
+  if (a->m > 0 && !a->kind && any_sparse_pair(a->L)) {
+    const int P = a->m * (a->m + 1) / 2;
+    a->sparse.resize(P);
+    DevBuf d_counts, d_base, d_keys, d_cnt;
+    std::vector<unsigned long long> counts(P, 0), base(P, 0);
+    HIP_TRY(d_counts.alloc(P * 8));
+    HIP_TRY(d_base.alloc(P * 8));
+    HIP_TRY(hipMemsetAsync(d_counts.p, 0, P * 8, st));
+    HIP_TRY(launch_tvec_sparse(*v, a->L, d_counts.as<unsigned long long>(), nullptr, nullptr, nullptr, 0, st));
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, P * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long total = 0;
+    for (int q = 0; q < P; q++) { base[q] = total; total += counts[q]; }
+    if (total) {
+      HIP_TRY(d_keys.alloc(total * 8));
+      HIP_TRY(d_cnt.alloc(total * 8));
+      HIP_TRY(hipMemcpyAsync(d_base.p, base.data(), P * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemsetAsync(d_counts.p, 0, P * 8, st));
+      HIP_TRY(launch_tvec_sparse(*v, a->L, d_counts.as<unsigned long long>(), d_base.as<unsigned long long>(),
+                                 d_keys.as<unsigned long long>(), d_cnt.as<unsigned long long>(), 1, st));
+      for (int q = 0; q < P; q++) {
+        if (!counts[q]) continue;
+        hipError_t e = sparse_merge_lists(ctx->sparse_sc, a->sparse[q], d_keys.as<unsigned long long>() + base[q],
+                                          d_cnt.as<unsigned long long>() + base[q], (size_t)counts[q], st);
+        if (e == hipErrorInvalidValue) return fail(COFACTOR_ERR_UNSUPPORTED, "a sparse pair table would pass 2^31 entries");
+        if (e != hipSuccess) return hip_fail(e, "sum_triple: sparse pair table");
+      }
+      HIP_TRY(hipStreamSynchronize(st));             // the lists above are freed on return
+    }
   }
   return COFACTOR_OK;
 }

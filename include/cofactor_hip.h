@@ -120,10 +120,10 @@ cofactor_status cofactor_agg_reset(cofactor_agg *agg);
  * are dense in the key's code).  A pair table (sum_no_lift.cpp:195-214) is dense, code-indexed,
  * while it has at most 2^26 cells and all dense pair tables together at most 2^30; beyond that the
  * pair is kept as a sorted (key1, key2) -> count list in device memory, like the reference's
- * std::map.  States that hold such lists work with update / combine / finalize / reset and with the
- * multi-GPU seam (the dense tables are aligned and all-reduced as usual, the lists are gathered and
- * merged: cofactor_agg_sparse_*, cofactor_agg_allreduce); sum_triple into them and the GROUP BY
- * pool return COFACTOR_ERR_UNSUPPORTED.
+ * std::map.  States that hold such lists work with update / sum_triple / combine / finalize / reset
+ * and with the multi-GPU seam (the dense tables are aligned and all-reduced as usual, the lists are
+ * gathered and merged: cofactor_agg_sparse_*, cofactor_agg_allreduce).  The GROUP BY pool
+ * (cofactor_groups) keeps dense per-group tables only and refuses cardinalities beyond them.
  *
  * Device form: the columns are resident in this context's HBM (d_num[k] -> float[rows],
  * d_cat[c] -> int32[rows]; the pointer arrays themselves are host arrays).  Asynchronous on the

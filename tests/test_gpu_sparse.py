@@ -107,6 +107,27 @@ def test_table_seam_takes_states_with_sorted_pair_lists(ctx):
     agg.close()
 
 
+def test_sum_triple_into_a_state_with_sorted_pair_lists(ctx):
+    """to_cofactor rows summed (sum_triple) into a state whose wide column pairs are kept as sorted
+    lists: their quad_cat entries are packed and merged into the stores (sum.cpp:246-260 adds into a
+    std::map); the narrow pair stays a dense table.  Device and host vectors, then plain rows on top."""
+    from cofactor_hip import ring
+    rng = np.random.default_rng(17)
+    num, cat = table(rng, 20_003, 2, (150, 6, 140))
+    h = 12_000
+    agg = ctx.aggregate(2, 3)
+    agg.update_device(to_gpu([c[:4000] for c in num]), to_gpu([c[:4000] for c in cat]))   # the layout: pairs (0,2) ... sparse
+    assert any(agg.sparse_is_list(q) for q in range(6)) and not all(agg.sparse_is_list(q) for q in range(6))
+    tv = ring.lift_device(ctx, to_gpu([c[4000:h] for c in num]), to_gpu([c[4000:h] for c in cat]))
+    ring.update_tvec(agg, tv)
+    tvh = ring.lift_host(ctx, [c[h:18_000] for c in num], [c[h:18_000] for c in cat])
+    ring.update_tvec(agg, tvh)
+    agg.update_device(to_gpu([c[18_000:] for c in num]), to_gpu([c[18_000:] for c in cat]))
+    got = blob_to_dict(agg.finalize())
+    agg.close()
+    assert got == want_of(num, cat)
+
+
 def test_two_wide_columns_at_real_size():
     """No override: two key columns with 70 000 and 60 000 distinct keys (code capacities 2^17 and
     2^16: 2^33 cells, far past what a dense table may take; also past the 16-bit code cache) next
