@@ -147,7 +147,8 @@ def self_launch(args, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+    launcher = os.environ.get("BENCH_LAUNCH_MODULE", "torch.distributed.run")   # (tests put a stand-in here)
+    cmd = [sys.executable, "-m", launcher, "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it here
@@ -155,7 +156,39 @@ def self_launch(args, argv):
     if os.environ.get("BENCH_LAUNCH_DRY_RUN"):             # tests: show the command, start nothing
         print(json.dumps({"launch": cmd}))
         return 0
-    return subprocess.call(cmd, env=env)
+    # The merge of the ranks' triples runs on the library's own RCCL communicator by default.  Should
+    # that attempt fail or stall (it has its own bootstrap: a second RCCL instance next to torch's),
+    # the ranks are stopped and started once more on torch.distributed's all_reduce, so that a scaling
+    # run still yields its line; `config.collective` says which collective was timed.
+    explicit = any(a == "--collective" or a.startswith("--collective=") for a in argv)
+    limit = float(os.environ.get("BENCH_LIB_TIMEOUT", "600"))
+    if explicit:
+        return subprocess.call(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        rc = None
+    if rc == 0:
+        return 0
+    if rc is None:                                         # our own process group, by its id
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            proc.wait(timeout=30)
+        except Exception:                                  # noqa: BLE001
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except Exception:                              # noqa: BLE001
+                pass
+            proc.wait()
+    sys.stderr.write("bench.py: the run on the library's communicator %s; once more with --collective torch\n"
+                     % ("did not finish in %.0f s" % limit if rc is None else "ended with code %d" % rc))
+    with socket.socket() as s2:
+        s2.bind(("127.0.0.1", 0))
+        port2 = s2.getsockname()[1]
+    cmd2 = [c if c != str(port) else str(port2) for c in cmd] + ["--collective", "torch"]
+    return subprocess.call(cmd2, env=env)
 
 
 def main():
@@ -217,10 +250,20 @@ def main():
             # every rank tries; the ranks then agree (one tiny torch all-reduce) whether ALL of them have
             # a communicator — a rank on its own inside the library's collective would hang the job
             err = None
+            # first agree that RCCL opens on every rank (the id call loads it): a rank that cannot even do
+            # that must not leave the others waiting inside ncclCommInitRank
             try:
-                comm = cdist.make_comm(ctx, dist)
+                cofactor_hip.comm_unique_id()
+                probe = 1
             except Exception as e:                   # noqa: BLE001 - reported in the JSON line
-                err = e
+                err, probe = e, 0
+            okp = torch.tensor([probe], dtype=torch.int32, device=device)
+            dist.all_reduce(okp, op=dist.ReduceOp.MIN)
+            if int(okp.item()) == 1:
+                try:
+                    comm = cdist.make_comm(ctx, dist)
+                except Exception as e:               # noqa: BLE001 - reported in the JSON line
+                    err = e
             ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:

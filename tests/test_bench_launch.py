@@ -50,3 +50,30 @@ def test_child_return_code_is_relayed(tmp_path):
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 7
     assert '"fake"' in out.stdout
+
+
+def _stub_env(**kw):
+    return _env(BENCH_LAUNCH_MODULE="fake_launcher", PYTHONPATH=os.path.join(ROOT, "tests"), **kw)
+
+
+def test_failed_run_on_the_library_communicator_is_repeated_on_the_torch_collective():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2"], env=_stub_env(),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["collective"] == "torch" and line["argv"][-2:] == ["--collective", "torch"]
+    assert "--steps" in line["argv"] and "once more with --collective torch" in out.stderr
+
+
+def test_stalled_run_on_the_library_communicator_is_stopped_and_repeated():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_stub_env(FAKE_LAUNCHER_STALL="1", BENCH_LIB_TIMEOUT="2"),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert json.loads(out.stdout.strip().splitlines()[-1])["config"]["collective"] == "torch"
+    assert "did not finish" in out.stderr
+
+
+def test_an_explicit_collective_is_not_second_guessed():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--collective", "lib"], env=_stub_env(),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3
