@@ -494,11 +494,17 @@ def sub(a, b):
 
 
 def _two_call_f32(fn, *args):
+    """The trainers' two-call protocol WITHOUT training twice: a buffer that holds any usual parameter
+    vector goes into the first call (a size query runs the whole training to learn the length); only
+    a longer result costs the second call."""
     need = C.c_uint64(0)
-    _check(fn(*args, None, 0, C.byref(need)))
-    out = np.empty(need.value, dtype=np.float32)
-    _check(fn(*args, out.ctypes.data, out.size, C.byref(need)))
-    return out
+    out = np.empty(1 << 16, dtype=np.float32)
+    st = fn(*args, out.ctypes.data, out.size, C.byref(need))
+    if st == ERR_CAPACITY:
+        out = np.empty(need.value, dtype=np.float32)
+        st = fn(*args, out.ctypes.data, out.size, C.byref(need))
+    _check(st)
+    return out[:need.value].copy()
 
 
 def linreg_train(triple, label, step_size=0.001, lam=0.0, max_iterations=10000,

@@ -201,27 +201,41 @@ namespace {
 
 // v = Sigma * theta: the one product both the gradient and the objective need (the reference
 // forms it twice per iteration, compute_gradient regression.cpp:27-46 and compute_error :48-77).
-// Eight partial sums per row so the loop vectorises; compiled for AVX-512 / AVX2 as well and
-// picked at load time (the descent calls this up to 10 000 times on a p x p matrix: it IS the
-// training time).  No contraction into FMAs: every clone rounds the same way.
+// Sigma is symmetric (build_sigma writes both halves), so v is also the sum of theta_j times ROW j:
+// 64 entries of v stay in registers while the rows stream by — vertical vector operations only, no
+// horizontal sum per row (the row-times-vector form with eight partial sums took 3.3 us at p = 171
+// on the bench host, this one 1.2).  Compiled for AVX-512 / AVX2 as well and picked at load time
+// (the descent calls this several hundred times on a p x p matrix: it IS the training time).  No
+// contraction into FMAs: every clone rounds the same way, each v[i] is the sum over j in order.
 #if defined(__x86_64__) && defined(__linux__)
 __attribute__((target_clones("avx512f", "avx2", "default")))
 #endif
 void sigma_times_raw(size_t p, const double *__restrict__ s, const double *__restrict__ th, double *__restrict__ v) {
 #pragma clang fp contract(off)
-  for (size_t i = 0; i < p; i++) {
-    const double *row = s + i * p;
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    size_t j = 0;
-    for (; j + 8 <= p; j += 8)
-      for (int u = 0; u < 8; u++) a[u] += row[j + u] * th[j + u];
-    double tail = 0;
-    for (; j < p; j++) tail += row[j] * th[j];
-    v[i] = (((a[0] + a[4]) + (a[1] + a[5])) + ((a[2] + a[6]) + (a[3] + a[7]))) + tail;
+  constexpr size_t B = 64;
+  for (size_t i0 = 0; i0 < p; i0 += B) {
+    const size_t w = p - i0 < B ? p - i0 : B;
+    double a[B];
+    for (size_t u = 0; u < B; u++) a[u] = 0;
+    if (w == B) {
+      for (size_t j = 0; j < p; j++) {
+        const double t = th[j];
+        const double *row = s + j * p + i0;
+        for (size_t u = 0; u < B; u++) a[u] += row[u] * t;
+      }
+    } else {
+      for (size_t j = 0; j < p; j++) {
+        const double t = th[j];
+        const double *row = s + j * p + i0;
+        for (size_t u = 0; u < w; u++) a[u] += row[u] * t;
+      }
+    }
+    for (size_t u = 0; u < w; u++) v[i0 + u] = a[u];
   }
 }
 void sigma_times(size_t p, const std::vector<double> &s, const std::vector<double> &th,
                  std::vector<double> &v) {
+
   sigma_times_raw(p, s.data(), th.data(), v.data());
 }
 

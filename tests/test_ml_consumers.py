@@ -303,3 +303,40 @@ def test_linreg_gradient_descent_reaches_the_normal_equations():
     X = np.stack([np.ones(rows), cols[1].astype(np.float64), cols[2].astype(np.float64)], 1)
     w = np.linalg.lstsq(X, cols[0].astype(np.float64), rcond=None)[0]
     assert np.allclose(p[1:], w, rtol=1e-3, atol=1e-3)
+
+
+def test_two_call_protocol_trains_once_and_never_mixes_up_calls():
+    """The C ABI's size query has to train; the call with the buffer that follows returns that very
+    result (per-thread memo keyed by the triple and every argument).  Another label, another triple
+    or another flag must not hit it."""
+    import ctypes as C
+    import time
+    tr, _ = _iris()
+    blob = np.ascontiguousarray(_triple(tr, COLS, ["target"]), dtype=np.float64)
+    L = cofactor_hip.lib()
+
+    def raw(b, label, variance, cap):
+        need = C.c_uint64(0)
+        out = np.zeros(max(cap, 1), dtype=np.float32)
+        st = L.cofactor_linreg_train(b.ctypes.data, b.size, label, 0.001, 0.0, 10000, int(variance), 0,
+                                     out.ctypes.data if cap else None, cap, C.byref(need))
+        return st, need.value, out[:need.value] if cap >= need.value else None
+
+    st, need, _ = raw(blob, 0, False, 0)
+    assert st == cofactor_hip.OK and need > 0
+    t0 = time.perf_counter()
+    st, need2, first = raw(blob, 0, False, need)
+    dt = time.perf_counter() - t0
+    assert st == cofactor_hip.OK and need2 == need
+    want = ml_oracle.linreg_train(blob_to_dict(blob), 0, 0.001, 0.0, 10000, False, False)
+    _close(first, want, 2e-4)
+    assert dt < 0.01                                    # no second training
+    other = cofactor_hip.linreg_train(blob, 1, 0.001, 0.0, 10000, False, False)
+    assert not np.allclose(other, first)
+    _close(other, ml_oracle.linreg_train(blob_to_dict(blob), 1, 0.001, 0.0, 10000, False, False), 2e-4)
+    with_var = cofactor_hip.linreg_train(blob, 0, 0.001, 0.0, 10000, True, False)
+    assert with_var.size == first.size + 1
+    changed = blob.copy()
+    changed[3] += 1.0                                   # (N)
+    assert not np.allclose(cofactor_hip.linreg_train(changed, 0, 0.001, 0.0, 10000, False, False), first)
+    assert raw(blob, 0, False, 1)[0] == cofactor_hip.ERR_CAPACITY
