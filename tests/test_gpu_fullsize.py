@@ -245,3 +245,36 @@ def test_20_0_one_billion_rows_exact_on_integer_table(ctx):
     # the first rows of the table are what the host-side generator says they are
     h, _ = synth.table_np(42, n, 0, 0, 1000, exact=16)
     assert all(np.array_equal(c[:1000].cpu().numpy(), hc) for c, hc in zip(cols, h))
+
+
+def test_group_by_20_0_segmented_at_150M_rows_exact(ctx):
+    """GROUP BY of sum_to_triple_20_0 through the segmented path (groupseg.hip) at a size that needs two
+    sub-batches (> 2^27 rows), key-typed groups, twice (the second call takes the counting pass as the
+    dictionary check): every group's N, and lin / a spread of quad cells of some groups, against torch
+    int64 sums over the group's rows."""
+    import torch
+    from cofactor_hip import ring
+    rows, n, G = 150_000_000, 20, 1000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    cols = [torch.randint(0, 8, (rows,), generator=g, device="cuda", dtype=torch.int32).float() for _ in range(n)]
+    slot = torch.randint(0, G, (rows,), generator=g, device="cuda", dtype=torch.int32)
+    gid = (slot * 37 - 5000).to(torch.int32)
+    torch.cuda.synchronize()
+    grp = ring.Groups(ctx, n, 0, is_key=True)
+    grp.update_device(gid, cols, [])
+    grp.update_device(gid, cols, [])
+    assert grp.count() == G
+    counts = torch.bincount(slot.long(), minlength=G)
+    for s_ in (0, 1, 499, 999):
+        got = blob_to_dict(grp.finalize(s_ * 37 - 5000))
+        sel = slot == s_
+        assert got["N"] == 2 * int(counts[s_])
+        ints = [c[sel].to(torch.int64) for c in cols]
+        assert got["lin_agg"] == [float(2 * int(v.sum())) for v in ints]
+        q = 0
+        for j in range(n):
+            for k in range(j, n):
+                if (j * 7 + k) % 11 == 0 or j == k:
+                    assert got["quad_agg"][q] == float(2 * int((ints[j] * ints[k]).sum())), (s_, j, k)
+                q += 1
+    grp.close()
