@@ -613,10 +613,14 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_sums_kernel(NumCols num, cons
       if (code == CODE_NONE) continue;
       atomicAdd(&l_c[c_base[c] + code], 1u);
       if (do_s) {
-        double *row = l_s + s_base[c] + (int)code * n;
+        // in LDS the sums of a column lie [numeric column][code]: the 64 lanes of one ds_add_f64 differ
+        // in the code only, and consecutive codes are consecutive banks ([code][numeric column], the
+        // order of the global table, puts codes 20 words apart at n = 10: 16 bank pairs for 64 lanes)
+        const int kc = L.kc[c];
+        double *col = l_s + s_base[c] + (int)code;
 #pragma unroll
         for (int k = 0; k < COFACTOR_MAX_NUM; k++)
-          if (k < n) unsafeAtomicAdd(&row[k], (double)x[k]);
+          if (k < n) unsafeAtomicAdd(&col[k * kc], (double)x[k]);
       }
     }
   }
@@ -626,8 +630,11 @@ __global__ __launch_bounds__(CAT_THREADS) void cat_sums_kernel(NumCols num, cons
     for (int i = tid; i < L.kc[c]; i += CAT_THREADS)
       if (l_c[c_base[c] + i]) atomicAdd(&D.cnt[L.cnt_off[c] + i], (unsigned long long)l_c[c_base[c] + i]);
     if (do_s)
-      for (int i = tid; i < L.kc[c] * n; i += CAT_THREADS)
-        if (l_s[s_base[c] + i] != 0.0) unsafeAtomicAdd(&D.s[L.s_off[c] + i], l_s[s_base[c] + i]);
+      for (int i = tid; i < L.kc[c] * n; i += CAT_THREADS) {          // i = code * n + k in the global table
+        const int code = i / n, k = i - code * n;
+        const double v = l_s[s_base[c] + k * L.kc[c] + code];
+        if (v != 0.0) unsafeAtomicAdd(&D.s[L.s_off[c] + i], v);
+      }
   }
 }
 
