@@ -19,6 +19,10 @@ run() { # name, extra bench args...   (KEY / KROWS: the traffic.json entry this 
   rm -rf $R/gpurun_out/${TAG}_${name}_trace $R/gpurun_out/${TAG}_${name}_fetch $R/gpurun_out/${TAG}_${name}_write $R/gpurun_out/${TAG}_${name}_trace.log
   echo "profiled $name"
 }
+if [ "$2" = "k64" ]; then
+  run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && echo k64 collected
+  exit 0
+fi
 if [ "$2" = "rest" ]; then
   run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && run 20_20 --total-rows 5e7 --num-cols 20 --cat-cols 20 \
     && run 10_10_k1000 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 1000 && echo rest collected
