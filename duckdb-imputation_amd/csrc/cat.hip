@@ -739,6 +739,10 @@ hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint
                            const CatLayout &L, const CatDevice &D, unsigned col_mask, int grid, hipStream_t stream) {
   if (rows == 0 || col_mask == 0) return hipSuccess;
   const bool do_s = L.kind == 0 && L.n > 0;
+  // 17 .. 64 codes per column: counts and sums on the matrix cores (catsums.hip); COFACTOR_NO_SUMS_MFMA=1: the LDS atomics
+  static const bool no_mfma = [] { const char *v = getenv("COFACTOR_NO_SUMS_MFMA"); return v && *v == '1'; }();
+  if (do_s && !no_mfma && cat_sums_mfma_applicable(L, col_mask, rows))
+    return launch_cat_sums_mfma(num, codes, rows, stride, L, D, col_mask, grid, stream);
   const size_t lds = cat_sums_lds_bytes(L, col_mask, do_s);
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)cat_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

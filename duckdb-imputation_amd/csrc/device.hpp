@@ -137,6 +137,10 @@ size_t cat_sums_lds_bytes(const CatLayout &L, unsigned col_mask, bool do_s);
 hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
                            const CatLayout &L, const CatDevice &D, unsigned col_mask, int grid, hipStream_t stream);
 // several column subsets (each fits LDS on its own) in ONE launch: the rows are read from HBM once
+// the same for key columns of 17 .. 64 codes, on the matrix cores (catsums.hip)
+bool cat_sums_mfma_applicable(const CatLayout &L, unsigned col_mask, uint64_t rows);
+hipError_t launch_cat_sums_mfma(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
+                                const CatLayout &L, const CatDevice &D, unsigned col_mask, int wgs, hipStream_t stream);
 hipError_t launch_cat_sums_subsets(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
                                    const CatLayout &L, const CatDevice &D, const unsigned *masks, int nsub, int cus,
                                    hipStream_t stream);

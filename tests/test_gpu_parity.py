@@ -827,3 +827,46 @@ def test_nb_ring_kernel_exact_at_any_cardinality(n, m, keys):
         c2.synchronize()
         agg.close()
     c2.close()
+
+
+@pytest.mark.parametrize("n,keys", [(10, (64,) * 10), (3, (17, 40, 64, 5)), (10, (33, 20, 64, 48, 7, 64, 30, 25, 61, 18, 64, 50)),
+                                    (1, (64, 64)), (5, (32, 31, 17))])
+def test_per_key_sums_of_17_to_64_keys_on_the_matrix_cores(ctx, n, keys):
+    """cat_sums_mfma_kernel (catsums.hip): key columns of 17 .. 64 keys — counts and per-key sums as
+    one-hot x bf16-piece products.  Exact on integer tables (also a row count that ends inside a tile,
+    two batches, a filtered batch), within 1e-5 of the wide oracle on floats, inf / nan only where the
+    oracle has them."""
+    import torch
+    rng = np.random.default_rng(sum(keys) + n)
+    rows, m = 40_037, len(keys)
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [(rng.integers(0, k, rows) * 3 - 17).astype(np.int32) for k in keys]
+    got = blob_to_dict(gpu_triple(ctx, num, cat))
+    want = blob_to_dict(orc.State(orc.FAITHFUL).update(num, cat).finalize())
+    assert got == want
+    # two batches, the second filtered
+    keep = (rng.random(rows) < 0.7).astype(np.uint8)
+    agg = ctx.aggregate(n, m)
+    dn = [torch.from_numpy(c).cuda() for c in num]
+    dc = [torch.from_numpy(c).cuda() for c in cat]
+    dk = torch.from_numpy(keep).cuda()
+    torch.cuda.synchronize()
+    agg.update_device(dn, dc)
+    agg.update_device_masked(dn, dc, dk)
+    got2 = blob_to_dict(agg.finalize())
+    agg.close()
+    sel = keep.astype(bool)
+    ref = orc.State(orc.FAITHFUL).update(num, cat).update([c[sel] for c in num], [c[sel] for c in cat])
+    assert got2 == blob_to_dict(ref.finalize())
+    # floats, and a non-finite value
+    fnum = [(rng.random(rows) * 200 - 100).astype(np.float32) for _ in range(n)]
+    fnum[0][123] = np.inf
+    g = blob_to_dict(gpu_triple(ctx, fnum, cat))
+    w = blob_to_dict(orc.State(orc.WIDE).update(fnum, cat).finalize())
+    assert g["lin_cat"] == w["lin_cat"] and g["quad_cat"] == w["quad_cat"]
+    for gl, wl in zip(g["quad_num_cat"], w["quad_num_cat"]):
+        assert [e["key"] for e in gl] == [e["key"] for e in wl]
+        gv, wv = np.array([e["value"] for e in gl], dtype=np.float64), np.array([e["value"] for e in wl], dtype=np.float64)
+        assert np.array_equal(np.isfinite(gv), np.isfinite(wv))
+        fin = np.isfinite(wv)
+        assert np.allclose(gv[fin], wv[fin], rtol=1e-5, atol=1e-3)

@@ -20,7 +20,7 @@ run() { # name, extra bench args...   (KEY / KROWS: the traffic.json entry this 
   echo "profiled $name"
 }
 if [ "$2" = "k64" ]; then
-  run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && echo k64 collected
+  run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && run 10_10_k32 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 32 && echo k64 collected
   exit 0
 fi
 if [ "$2" = "rest" ]; then
