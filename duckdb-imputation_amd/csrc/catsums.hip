@@ -66,9 +66,11 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
   }
   __syncthreads();
   const int nsel = l_nsel, W1 = n + 1;                 // table row: n sums, then the count
-  unsigned short *pt = reinterpret_cast<unsigned short *>(lds_raw);               // [16 NBB piece columns][CS_PST bytes]
-  double *l_tab = reinterpret_cast<double *>(lds_raw + 16 * NBB * CS_PST);        // [selected column][16 KB codes][n + 1]
-  for (int i = tid; i < 16 * NBB * CS_PST / 2; i += CS_TW) pt[i] = 0;
+  // two piece buffers, [16 NBB piece columns][CS_PST bytes] each: a tile is written into one while the
+  // slower waves may still read the other — ONE barrier per tile
+  unsigned short *pt0 = reinterpret_cast<unsigned short *>(lds_raw);
+  double *l_tab = reinterpret_cast<double *>(lds_raw + 2 * 16 * NBB * CS_PST);    // [selected column][16 KB codes][n + 1]
+  for (int i = tid; i < 2 * 16 * NBB * CS_PST / 2; i += CS_TW) pt0[i] = 0;
   for (int i = tid; i < nsel * KB * 16 * W1; i += CS_TW) l_tab[i] = 0.0;
   int myc[CS_MC];
 #pragma unroll
@@ -90,10 +92,10 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
   // Every load is issued unconditionally (addresses clamped, results overridden afterwards): a load
   // inside a branch makes the number of loads in flight unknown to the compiler, which then waits
   // for ALL of them (s_waitcnt vmcnt(0)) before the first use — the prefetch of the next tile included.
-  const uint64_t last_row = rows - 1;
   auto fetch = [&](uint64_t tile) {
     const uint64_t row0 = tile * CS_TILE;
-    const uint64_t xr = min(row0 + r, last_row);
+    const int rem = (int)min<uint64_t>(rows - row0, (uint64_t)CS_TILE);   // rows of this tile (wave-uniform)
+    const uint64_t xr = row0 + (r < rem ? r : 0);
 #pragma unroll
     for (int q = 0; q < XQ; q++) {
       const int j = min(j0 + CS_NW * q, n - 1);
@@ -105,9 +107,9 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
       for (int h = 0; h < 2; h++) {
         // (the cache is written four rows at a time, CODE_NONE past the end: a group of four that
         //  starts below `rows` is whole)
-        const uint64_t base = row0 + 32 * h + 8 * g;
-        const uint64_t b0 = base < rows ? base : 0, b1 = base + 4 < rows ? base + 4 : 0;
-        const unsigned short *col = codes + (uint64_t)(myc[ci] >= 0 ? myc[ci] : myc[0]) * stride;
+        const int off = 32 * h + 8 * g;
+        const int b0 = off < rem ? off : 0, b1 = off + 4 < rem ? off + 4 : 0;
+        const unsigned short *col = codes + (uint64_t)(myc[ci] >= 0 ? myc[ci] : myc[0]) * stride + row0;
         cn[ci][h][0] = *reinterpret_cast<const uint2 *>(col + b0);
         cn[ci][h][1] = *reinterpret_cast<const uint2 *>(col + b1);
       }
@@ -115,16 +117,17 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
   // what the clamped loads fetched in place of rows past the end / columns this wave does not have
   auto settle = [&](uint64_t tile, float (&xc)[XQ], uint2 (&cc)[CS_MC][2][2]) {
     const uint64_t row0 = tile * CS_TILE;
+    const int rem = (int)min<uint64_t>(rows - row0, (uint64_t)CS_TILE);
     const uint2 none = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 #pragma unroll
-    for (int q = 0; q < XQ; q++) xc[q] = (j0 + CS_NW * q < n && row0 + r < rows) ? xn[q] : 0.f;
+    for (int q = 0; q < XQ; q++) xc[q] = (j0 + CS_NW * q < n && r < rem) ? xn[q] : 0.f;
 #pragma unroll
     for (int ci = 0; ci < CS_MC; ci++)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const uint64_t base = row0 + 32 * h + 8 * g;
-        cc[ci][h][0] = (myc[ci] >= 0 && base < rows) ? cn[ci][h][0] : none;
-        cc[ci][h][1] = (myc[ci] >= 0 && base + 4 < rows) ? cn[ci][h][1] : none;
+        const int off = 32 * h + 8 * g;
+        cc[ci][h][0] = (myc[ci] >= 0 && off < rem) ? cn[ci][h][0] : none;
+        cc[ci][h][1] = (myc[ci] >= 0 && off + 4 < rem) ? cn[ci][h][1] : none;
       }
   };
   auto fold = [&]() {
@@ -150,9 +153,10 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
 
   uint64_t tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
-  int since = 0;
+  int since = 0, buf = 0;
   __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    unsigned short *pt = pt0 + buf * (16 * NBB * CS_PST / 2);
     // ---- the tile's values into bf16 pieces, B-operand order ----
     const uint64_t row0 = tile * CS_TILE;
     float xc[XQ];
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
     for (int h = 0; h < 2; h++)
 #pragma unroll
       for (int bb = 0; bb < NBB; bb++)
-        bop[h][bb] = __builtin_bit_cast(cs_bf16x8, *reinterpret_cast<const uint4 *>(lds_raw + (16 * bb + n16) * CS_PST + (32 * h + 8 * g) * 2));
+        bop[h][bb] = __builtin_bit_cast(cs_bf16x8, *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(pt) + (16 * bb + n16) * CS_PST + (32 * h + 8 * g) * 2));
 #pragma unroll
     for (int ci = 0; ci < CS_MC; ci++) {
       if (myc[ci] < 0) continue;
@@ -207,7 +211,6 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
       }
     }
     if (++since == CS_FOLD_TILES) { fold(); since = 0; }
-    __syncthreads();                                   // the pieces may be overwritten
   }
   fold();
   __syncthreads();
@@ -242,7 +245,7 @@ hipError_t launch_cat_sums_mfma(const NumCols &num, const unsigned short *codes,
   for (int c = 0; c < L.m; c++)
     if ((col_mask >> c) & 1u) { nsel++; kmax = std::max(kmax, L.kc[c]); }
   const int KB = (kmax + 15) / 16, NBB = (3 * L.n + 1 + 15) / 16;
-  const size_t lds = (size_t)16 * NBB * CS_PST + (size_t)nsel * KB * 16 * (L.n + 1) * 8;
+  const size_t lds = (size_t)2 * 16 * NBB * CS_PST + (size_t)nsel * KB * 16 * (L.n + 1) * 8;
   const uint64_t ntiles = (rows + CS_TILE - 1) / CS_TILE;
   const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)std::max(wgs, 1));
 #define CS_CASE(K, B)                                                                                              \
