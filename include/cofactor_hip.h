@@ -355,7 +355,12 @@ cofactor_status cofactor_agg_update_tvec_device(cofactor_agg *agg, const cofacto
  * COFACTOR_ERR_CAPACITY) only *lc_need / *nc_need / *cc_need are set (entries of the three payload
  * arrays).  N is the int32 product, as in the reference (mul.cpp:46-49).  The size query
  * synchronises (it returns numbers); the fill is asynchronous on the context stream like the other
- * device entry points (cofactor_ctx_synchronize before another stream reads `out`). */
+ * device entry points (cofactor_ctx_synchronize before another stream reads `out`).
+ * The size query leaves its plan (the rows' payload sizes and places) with the context; the fill call
+ * that FOLLOWS it with the same a / b / selection vectors / rows takes the plan over instead of
+ * computing it again — the inputs must not be modified between the two calls.  A fill call without
+ * such a query (capacities known to suffice) computes the plan itself: one call, one synchronisation.
+ * GROUP BY pool, numeric-only triples: see cofactor_groups_update_device below. */
 cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec *a,
                                          const uint32_t *d_a_sel, const cofactor_tvec *b,
                                          const uint32_t *d_b_sel, uint64_t rows, cofactor_tvec *out,
@@ -380,6 +385,9 @@ cofactor_status cofactor_multiply_host(cofactor_ctx *ctx, const cofactor_tvec *a
  * join key with 1e5 values costs 1e5 table rows, not 1e5 states with their own buffers.
  *   gid: group of every row — slot ids 0..G-1 handed out by the caller (is_key = 0; the DuckDB
  *        glue numbers its SumStates), or arbitrary int32 keys (is_key = 1; GROUP BY column).
+ * update:  numeric-only triples (n_cat = 0) with many rows per group in the batch regroup the batch by
+ *          group and run one matrix-core Gram per group (csrc/groupseg.hip, scratch of 132 B per row
+ *          at 20_0 kept by the context); everything else adds cell by cell with fp64 atomics.
  * combine: Triple::SumStateCombine per group (dst += src; src unchanged).
  * finalize: one group's triple as a flat blob (two-call protocol), keys ascending.
  * to_tvec: every group's triple, in ascending group order (is_key = 1: ascending key; the keys go to
