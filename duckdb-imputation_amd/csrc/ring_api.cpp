@@ -71,6 +71,11 @@ struct cofactor_groups {
   std::vector<std::vector<int32_t>> key_of;    // [column][code] -> key
   std::vector<int32_t> group_key;              // [group row] -> key (is_key)
   std::map<int32_t, int32_t> group_of_key;
+  // host batches (DataChunks of 2048 rows) are collected in pinned memory, [group id | columns][stage_cap]
+  // words, and reach the device stage_cap rows at a time (groups_flush): one staging copy and one
+  // update per 2^18 rows instead of per chunk — and batches big enough for the segmented path
+  uint32_t *h_stage = nullptr, *d_stage = nullptr;
+  uint64_t stage_cap = 0, stage_fill = 0;
 };
 
 namespace {
@@ -568,7 +573,13 @@ void cofactor_groups_destroy(cofactor_groups *g) {
   cat_free(g->D);
   cat_free(g->Dg);
   (void)hipFree(g->tab);
+  (void)hipFree(g->d_stage);
+  (void)hipHostFree(g->h_stage);
   delete g;
+}
+
+extern "C++" {
+namespace { cofactor_status groups_flush(cofactor_groups *g); }
 }
 
 cofactor_status cofactor_groups_update_device(cofactor_groups *g, const int32_t *d_gid, const float *const *d_num,
@@ -583,6 +594,10 @@ cofactor_status cofactor_groups_update_device(cofactor_groups *g, const int32_t 
   CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   hipStream_t st = ctx->stream;
+  if (g->stage_fill) {                               // host rows collected earlier go first
+    cofactor_status fs = groups_flush(g);
+    if (fs != COFACTOR_OK) return fs;
+  }
   // wide numeric triples with many rows per group take the segmented path (groupseg.hip)
   constexpr uint64_t SEG_MAX_ROWS = 1ull << 27;
   const bool seg_shape = g->m == 0 && g->kind == 0 && g->n >= 1;
@@ -698,39 +713,71 @@ cofactor_status cofactor_groups_update_device(cofactor_groups *g, const int32_t 
   return COFACTOR_OK;
 }
 
+extern "C++" {
+namespace {
+// staged host rows -> device -> tables.  Called (under the context lock) by every entry point that
+// looks at the pool's state.
+cofactor_status groups_flush(cofactor_groups *g) {
+  const uint64_t rows = g->stage_fill;
+  if (rows == 0) return COFACTOR_OK;
+  g->stage_fill = 0;                                  // (update_device flushes too: not twice)
+  cofactor_ctx *ctx = g->ctx;
+  const size_t ncol = (size_t)g->n + g->m + 1;
+  const float *dn[COFACTOR_MAX_NUM];
+  const int32_t *dc[COFACTOR_MAX_CAT];
+  for (size_t col = 0; col < ncol; col++)
+    HIP_TRY(hipMemcpyAsync(g->d_stage + col * g->stage_cap, g->h_stage + col * g->stage_cap, rows * 4, hipMemcpyHostToDevice, ctx->stream));
+  for (int k = 0; k < g->n; k++) dn[k] = reinterpret_cast<const float *>(g->d_stage + (size_t)(1 + k) * g->stage_cap);
+  for (int c = 0; c < g->m; c++) dc[c] = reinterpret_cast<const int32_t *>(g->d_stage + (size_t)(1 + g->n + c) * g->stage_cap);
+  cofactor_status s = cofactor_groups_update_device(g, reinterpret_cast<const int32_t *>(g->d_stage), dn, dc, rows);
+  hipError_t e = hipStreamSynchronize(ctx->stream);   // the pinned block is written again by the next batch
+  if (s != COFACTOR_OK) return s;
+  if (e != hipSuccess) return hip_fail(e, "groups_flush");
+  return COFACTOR_OK;
+}
+}  // namespace
+}
+
 cofactor_status cofactor_groups_update_host(cofactor_groups *g, const int32_t *gid, const float *const *num,
                                             const int32_t *const *cat, uint64_t rows) {
   if (!g || (rows && !gid) || (g->n > 0 && !num) || (g->m > 0 && !cat)) return fail(COFACTOR_ERR_INVALID, "null argument");
   if (rows == 0) return COFACTOR_OK;
+  for (int k = 0; k < g->n; k++) if (!num[k]) return fail(COFACTOR_ERR_INVALID, "null column");
+  for (int c = 0; c < g->m; c++) if (!cat[c]) return fail(COFACTOR_ERR_INVALID, "null column");
   cofactor_ctx *ctx = g->ctx;
   CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
-  DevBuf buf;
   const size_t ncol = (size_t)g->n + g->m + 1;
-  HIP_TRY(buf.alloc(ncol * rows * 4));
-  uint32_t *d = buf.as<uint32_t>();
-  const float *dn[COFACTOR_MAX_NUM];
-  const int32_t *dc[COFACTOR_MAX_CAT];
-  HIP_TRY(hipMemcpyAsync(d, gid, rows * 4, hipMemcpyHostToDevice, ctx->stream));
-  for (int k = 0; k < g->n; k++) {
-    if (!num[k]) return fail(COFACTOR_ERR_INVALID, "null column");
-    dn[k] = reinterpret_cast<const float *>(d + (size_t)(1 + k) * rows);
-    HIP_TRY(hipMemcpyAsync((void *)dn[k], num[k], rows * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!g->h_stage) {
+    const uint64_t cap = std::max<uint64_t>(ctx->stage_rows_max, 1u << 18);
+    HIP_TRY(hipHostMalloc((void **)&g->h_stage, ncol * cap * 4, hipHostMallocDefault));
+    hipError_t e = hipMalloc((void **)&g->d_stage, ncol * cap * 4);
+    if (e != hipSuccess) { (void)hipHostFree(g->h_stage); g->h_stage = nullptr; return hip_fail(e, "groups staging"); }
+    g->stage_cap = cap;
   }
-  for (int c = 0; c < g->m; c++) {
-    if (!cat[c]) return fail(COFACTOR_ERR_INVALID, "null column");
-    dc[c] = reinterpret_cast<const int32_t *>(d + (size_t)(1 + g->n + c) * rows);
-    HIP_TRY(hipMemcpyAsync((void *)dc[c], cat[c], rows * 4, hipMemcpyHostToDevice, ctx->stream));
+  for (uint64_t done = 0; done < rows;) {
+    const uint64_t take = std::min(rows - done, g->stage_cap - g->stage_fill);
+    std::memcpy(g->h_stage + g->stage_fill, gid + done, take * 4);
+    for (int k = 0; k < g->n; k++) std::memcpy(g->h_stage + (size_t)(1 + k) * g->stage_cap + g->stage_fill, num[k] + done, take * 4);
+    for (int c = 0; c < g->m; c++) std::memcpy(g->h_stage + (size_t)(1 + g->n + c) * g->stage_cap + g->stage_fill, cat[c] + done, take * 4);
+    g->stage_fill += take;
+    done += take;
+    if (g->stage_fill == g->stage_cap) {
+      cofactor_status s = groups_flush(g);
+      if (s != COFACTOR_OK) return s;
+    }
   }
-  cofactor_status s = cofactor_groups_update_device(g, reinterpret_cast<const int32_t *>(d), dn, dc, rows);
-  hipError_t e = hipStreamSynchronize(ctx->stream);   // the staging buffer is freed on return
-  if (s != COFACTOR_OK) return s;
-  if (e != hipSuccess) return hip_fail(e, "groups_update_host");
   return COFACTOR_OK;
 }
 
 cofactor_status cofactor_groups_count(cofactor_groups *g, uint64_t *n_groups) {
   if (!g || !n_groups) return fail(COFACTOR_ERR_INVALID, "null argument");
+  {
+    CTX_LOCK(g->ctx);
+    DeviceGuard guard(g->ctx->device);
+    cofactor_status s = groups_flush(g);
+    if (s != COFACTOR_OK) return s;
+  }
   *n_groups = (uint64_t)g->groups;
   return COFACTOR_OK;
 }
@@ -753,7 +800,9 @@ cofactor_status cofactor_groups_combine(cofactor_groups *g, int32_t dst_gid, int
   CTX_LOCK(g->ctx);
   DeviceGuard guard(g->ctx->device);
   long long dst, src;
-  cofactor_status s = group_row(g, dst_gid, &dst);
+  cofactor_status s = groups_flush(g);
+  if (s != COFACTOR_OK) return s;
+  s = group_row(g, dst_gid, &dst);
   if (s == COFACTOR_OK) s = group_row(g, src_gid, &src);
   if (s != COFACTOR_OK) return s;
   if (dst < 0 || src < 0 || dst == src) return fail(COFACTOR_ERR_INVALID, "combine: no such group (or a group with itself)");
@@ -765,7 +814,8 @@ cofactor_status cofactor_groups_finalize(cofactor_groups *g, int32_t gid, double
   if (!g) return fail(COFACTOR_ERR_INVALID, "null argument");
   CTX_LOCK(g->ctx);
   DeviceGuard guard(g->ctx->device);
-  cofactor_status s = groups_refresh_host(g);
+  cofactor_status s = groups_flush(g);
+  if (s == COFACTOR_OK) s = groups_refresh_host(g);
   if (s != COFACTOR_OK) return s;
   long long rowi;
   s = group_row(g, gid, &rowi);
@@ -817,7 +867,8 @@ cofactor_status cofactor_groups_to_tvec(cofactor_groups *g, cofactor_tvec *out, 
   CTX_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   hipStream_t st = ctx->stream;
-  cofactor_status s = groups_refresh_host(g);
+  cofactor_status s = groups_flush(g);
+  if (s == COFACTOR_OK) s = groups_refresh_host(g);
   if (s != COFACTOR_OK) return s;
   const CatLayout &L = g->L;
   const int n = g->n, m = g->m, kind = g->kind;

@@ -388,6 +388,9 @@ cofactor_status cofactor_multiply_host(cofactor_ctx *ctx, const cofactor_tvec *a
  * update:  numeric-only triples (n_cat = 0) with many rows per group in the batch regroup the batch by
  *          group and run one matrix-core Gram per group (csrc/groupseg.hip, scratch of 132 B per row
  *          at 20_0 kept by the context); everything else adds cell by cell with fp64 atomics.
+ *          Host batches (update_host) are collected in a pinned staging block and reach the device 2^18
+ *          rows at a time, or when another entry point looks at the pool (count, combine, finalize,
+ *          to_tvec, update_device); a device error of staged rows is reported by that later call.
  * combine: Triple::SumStateCombine per group (dst += src; src unchanged).
  * finalize: one group's triple as a flat blob (two-call protocol), keys ascending.
  * to_tvec: every group's triple, in ascending group order (is_key = 1: ascending key; the keys go to

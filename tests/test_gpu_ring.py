@@ -275,6 +275,35 @@ def test_segmented_group_by_matches_the_atomic_path_on_real_values():
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,m", [(20, 0), (3, 2)])
+def test_group_by_pool_collects_host_chunks_before_it_goes_to_the_device(ctx, n, m):
+    """DataChunk-sized host batches (2048 rows) are staged in pinned memory and reach the device 2^18
+    rows at a time (and then, for numeric triples, through the segmented path); count / finalize /
+    combine in between see every row handed over so far."""
+    rng = np.random.default_rng(31 + n)
+    G, chunk, nchunks = 40, 2048, 300                     # 614 400 rows: two full staging blocks and a rest
+    rows = chunk * nchunks
+    slot = rng.integers(0, G, rows).astype(np.int32)
+    slot[:chunk] = np.arange(chunk) % 7                   # the first chunk knows seven groups only
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [rng.integers(-3, 4, rows).astype(np.int32) for _ in range(m)]
+    grp = ring.Groups(ctx, n, m, cofactor_hip.TRIPLE, is_key=True)
+    keys = (np.arange(G, dtype=np.int32) * 5 - 60)
+    gid = keys[slot]
+    grp.update_host(gid[:chunk], [c[:chunk] for c in num], [c[:chunk] for c in cat])
+    assert grp.count() == 7                               # (flushes what has been staged)
+    first = orc.grouped_update([c[:chunk] for c in num], [c[:chunk] for c in cat], slot[:chunk], G, nb=False)
+    assert blob_to_dict(grp.finalize(int(keys[3]))) == blob_to_dict(first[3].finalize())
+    for i in range(1, nchunks):
+        a, b = i * chunk, (i + 1) * chunk
+        grp.update_host(gid[a:b], [c[a:b] for c in num], [c[a:b] for c in cat])
+    assert grp.count() == G
+    want = orc.grouped_update(num, cat, slot, G, nb=False)
+    for s_ in range(0, G, 3):
+        assert blob_to_dict(grp.finalize(int(keys[s_]))) == blob_to_dict(want[s_].finalize()), s_
+    grp.close()
+
+
 def _join_tables(G, per, seed):
     rng = np.random.default_rng(seed)
     rows = G * per
