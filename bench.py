@@ -164,7 +164,30 @@ def self_launch(args, argv):
     limit = float(os.environ.get("BENCH_LIB_TIMEOUT", "600"))
     if explicit:
         return subprocess.call(cmd, env=env)
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    import signal
+
+    def own_session():
+        # a session of its own (so that a stalled attempt can be stopped as a group) that still ends
+        # with this process: SIGTERM to the launcher when the parent dies, however it dies
+        os.setsid()
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)     # PR_SET_PDEATHSIG
+        except Exception:                                  # noqa: BLE001
+            pass
+
+    proc = subprocess.Popen(cmd, env=env, preexec_fn=own_session)
+    live = [proc]
+
+    def relay(signum, _frame):                             # the driver stops us: stop the ranks too
+        try:
+            os.killpg(live[0].pid, signal.SIGTERM)
+        except Exception:                                  # noqa: BLE001
+            pass
+        sys.exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, relay)
     try:
         rc = proc.wait(timeout=limit)
     except subprocess.TimeoutExpired:
@@ -172,7 +195,6 @@ def self_launch(args, argv):
     if rc == 0:
         return 0
     if rc is None:                                         # our own process group, by its id
-        import signal
         try:
             os.killpg(proc.pid, signal.SIGTERM)
             proc.wait(timeout=30)
@@ -188,7 +210,8 @@ def self_launch(args, argv):
         s2.bind(("127.0.0.1", 0))
         port2 = s2.getsockname()[1]
     cmd2 = [c if c != str(port) else str(port2) for c in cmd] + ["--collective", "torch"]
-    return subprocess.call(cmd2, env=env)
+    live[0] = subprocess.Popen(cmd2, env=env, preexec_fn=own_session)
+    return live[0].wait()
 
 
 def main():
