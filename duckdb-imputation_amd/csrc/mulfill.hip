@@ -277,14 +277,23 @@ hipError_t launch_mul_pair_lens(const cofactor_tvec &a, const uint32_t *asel, co
 
 hipError_t launch_mul_fill(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
                            uint64_t rows, const uint64_t *base0, const uint64_t *base1, const uint64_t *base2,
-                           const cofactor_tvec &out, int cus, hipStream_t stream) {
+                           const cofactor_tvec &out, uint64_t entries, int cus, hipStream_t stream) {
   if (rows == 0) return hipSuccess;
   const int mR = a.m + b.m, nR = a.n + b.n;
   const int PT = mR + (a.kind ? 0 : nR * mR + mR * (mR + 1) / 2);
   static const int dev_gl = [] { const char *v = getenv("COFACTOR_MUL_GL"); return v ? atoi(v) : 0; }();
-  // lanes per output row: 2_2 x 2_2 (30 sub-lists, 192 entries), 2e6 rows: 64 -> 7.3 ms, 32 -> 5.2, 16 -> 4.3, 8 -> 3.8
-  const int gl = dev_gl ? dev_gl : (PT <= 40 ? 8 : (PT <= 128 ? 16 : (PT <= 320 ? 32 : 64)));
-  if (gl == 8) {
+  // lanes per output row: 2_2 x 2_2 (30 sub-lists), 2e6 rows, 192 entries per row: 64 -> 7.3 ms, 32 -> 5.2,
+  // 16 -> 4.3, 8 -> 3.8 (then four entries per lane in flight: 8 -> 3.4); 1 685 entries per row (16 keys per
+  // column): 8 -> 22.7 ms, 16 -> 20.6, 32 -> 20.1, 64 -> 22.5
+  const uint64_t per_row = entries / std::max<uint64_t>(rows, 1);
+  int gl = PT <= 40 ? 8 : (PT <= 128 ? 16 : (PT <= 320 ? 32 : 64));
+  if (per_row > 256) gl = std::max(gl, 16);
+  if (per_row > 1024) gl = std::max(gl, 32);
+  if (dev_gl) gl = dev_gl;
+  if (gl == 4) {
+    const unsigned grid = (unsigned)std::min<uint64_t>((rows + 63) / 64, (uint64_t)cus * 8);
+    hipLaunchKernelGGL(mul_fill_kernel<4>, dim3(grid), dim3(256), 0, stream, a, asel, b, bsel, rows, base0, base1, base2, out);
+  } else if (gl == 8) {
     const unsigned grid = (unsigned)std::min<uint64_t>((rows + 31) / 32, (uint64_t)cus * 8);
     hipLaunchKernelGGL(mul_fill_kernel<8>, dim3(grid), dim3(256), 0, stream, a, asel, b, bsel, rows, base0, base1, base2, out);
   } else if (gl == 32) {

@@ -21,7 +21,7 @@ hipError_t launch_mul_pair_lens(const cofactor_tvec &a, const uint32_t *asel, co
                                 uint64_t rows, uint64_t *t0, uint64_t *t1, uint64_t *t2, hipStream_t stream);
 hipError_t launch_mul_fill(const cofactor_tvec &a, const uint32_t *asel, const cofactor_tvec &b, const uint32_t *bsel,
                            uint64_t rows, const uint64_t *base0, const uint64_t *base1, const uint64_t *base2,
-                           const cofactor_tvec &out, int cus, hipStream_t stream);
+                           const cofactor_tvec &out, uint64_t entries, int cus, hipStream_t stream);
 hipError_t ring_exclusive_scan(const uint64_t *len, uint64_t *offs, uint64_t items, void *temp, size_t *temp_bytes,
                                hipStream_t stream);
 

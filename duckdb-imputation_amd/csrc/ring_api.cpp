@@ -318,7 +318,7 @@ cofactor_status cofactor_multiply_device(cofactor_ctx *ctx, const cofactor_tvec 
   if (out->lc_cap < need[0] || out->nc_cap < need[1] || out->cc_cap < need[2])
     return fail(COFACTOR_ERR_CAPACITY, "multiply: payload arrays too small");
   if (!tvec_dense_ok(out) || !tvec_lists_ok(out)) return fail(COFACTOR_ERR_INVALID, "multiply: an output array is null");
-  HIP_TRY(launch_mul_fill(*a, d_a_sel, *b, d_b_sel, rows, base[0], base[1], base[2], *out, ctx->cus, st));
+  HIP_TRY(launch_mul_fill(*a, d_a_sel, *b, d_b_sel, rows, base[0], base[1], base[2], *out, need[0] + need[1] + need[2], ctx->cus, st));
   // (asynchronous from here, like every device entry point: the scratch block stays the context's)
   return COFACTOR_OK;
 }
