@@ -425,7 +425,8 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
   }
   if (e0) HIP_TRY(hipEventRecord(e0, st));
   for (uint64_t off = 0; off < rows; off += piece) {
-    const uint64_t prows = std::min(piece, rows - off), stride = (prows + 3) / 4 * 4;
+    // (a column of the code cache: whole 64-row tiles, CODE_NONE behind the last row — catsums.hip reads tiles)
+    const uint64_t prows = std::min(piece, rows - off), stride = (prows + 63) / 64 * 64;
     NumCols pn = num;
     CatCols pc = cat;
     for (int k = 0; k < L.n; k++) pn.p[k] = num.p[k] + off;

@@ -570,6 +570,12 @@ __global__ __launch_bounds__(256) void cat_codes_kernel(CatCols cat, uint64_t ro
       *reinterpret_cast<uint2 *>(codes + (uint64_t)c * stride + r) = make_uint2(out[0] | ((unsigned)out[1] << 16), out[2] | ((unsigned)out[3] << 16));
     }
   }
+  // behind the last group of four, up to the end of its 64-row tile: CODE_NONE (the stride covers it)
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const uint64_t pad = (rows + 3) / 4 * 4 + threadIdx.x, end = (rows + 63) / 64 * 64;
+    if (pad < end)
+      for (int c = 0; c < L.m; c++) codes[(uint64_t)c * stride + pad] = CODE_NONE;
+  }
 }
 
 // counts and sums of the key columns in col_mask (their tables: cnt u32 [kc], then s f64 [kc][n]).
@@ -741,7 +747,7 @@ hipError_t launch_cat_sums(const NumCols &num, const unsigned short *codes, uint
   const bool do_s = L.kind == 0 && L.n > 0;
   // 17 .. 64 codes per column: counts and sums on the matrix cores (catsums.hip); COFACTOR_NO_SUMS_MFMA=1: the LDS atomics
   static const bool no_mfma = [] { const char *v = getenv("COFACTOR_NO_SUMS_MFMA"); return v && *v == '1'; }();
-  if (do_s && !no_mfma && cat_sums_mfma_applicable(L, col_mask, rows))
+  if (do_s && !no_mfma && stride % 64 == 0 && cat_sums_mfma_applicable(L, col_mask, rows))
     return launch_cat_sums_mfma(num, codes, rows, stride, L, D, col_mask, grid, stream);
   const size_t lds = cat_sums_lds_bytes(L, col_mask, do_s);
   if (lds > 48 * 1024) {

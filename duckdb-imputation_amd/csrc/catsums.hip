@@ -105,29 +105,26 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
     for (int ci = 0; ci < CS_MC; ci++)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        // (the cache is written four rows at a time, CODE_NONE past the end: a group of four that
-        //  starts below `rows` is whole)
-        const int off = 32 * h + 8 * g;
-        const int b0 = off < rem ? off : 0, b1 = off + 4 < rem ? off + 4 : 0;
+        // (a column of the cache is whole 64-row tiles, CODE_NONE behind the last row: no clamping here)
+        const unsigned off = 32u * h + 8u * g;
         const unsigned short *col = codes + (uint64_t)(myc[ci] >= 0 ? myc[ci] : myc[0]) * stride + row0;
-        cn[ci][h][0] = *reinterpret_cast<const uint2 *>(col + b0);
-        cn[ci][h][1] = *reinterpret_cast<const uint2 *>(col + b1);
+        const uint4 v = *reinterpret_cast<const uint4 *>(col + off);
+        cn[ci][h][0] = make_uint2(v.x, v.y);
+        cn[ci][h][1] = make_uint2(v.z, v.w);
       }
   };
   // what the clamped loads fetched in place of rows past the end / columns this wave does not have
   auto settle = [&](uint64_t tile, float (&xc)[XQ], uint2 (&cc)[CS_MC][2][2]) {
     const uint64_t row0 = tile * CS_TILE;
     const int rem = (int)min<uint64_t>(rows - row0, (uint64_t)CS_TILE);
-    const uint2 none = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 #pragma unroll
     for (int q = 0; q < XQ; q++) xc[q] = (j0 + CS_NW * q < n && r < rem) ? xn[q] : 0.f;
 #pragma unroll
     for (int ci = 0; ci < CS_MC; ci++)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int off = 32 * h + 8 * g;
-        cc[ci][h][0] = (myc[ci] >= 0 && off < rem) ? cn[ci][h][0] : none;
-        cc[ci][h][1] = (myc[ci] >= 0 && off + 4 < rem) ? cn[ci][h][1] : none;
+        cc[ci][h][0] = cn[ci][h][0];                   // (a column this wave does not have is skipped below)
+        cc[ci][h][1] = cn[ci][h][1];
       }
   };
   auto fold = [&]() {
