@@ -382,19 +382,26 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
   const int groups_n = (L.n + 9) / 10, groups_m = (L.m + 9) / 10;
   bool small_keys = L.kind == 0 && ctx->allow_fused && rows >= 16 * FUSED_TILE_ROWS && !ctx->no_sub;
   for (int c = 0; c < L.m; c++) small_keys = small_keys && a->nkeys_host[c] <= 16 && L.kc[c] == 16;
-  const bool mfma_sums = small_keys && do_s && sums_fit &&
+  // (more than 10 key columns: their pair tables need the code cache anyway, and the per-key sums then come
+  //  from it too — cat_sums_mfma_kernel over <= 12 key columns x all numeric columns reads less than the
+  //  sub-launches over 10 x 10 groups of raw keys)
+  const bool mfma_sums = small_keys && do_s && sums_fit && L.m <= 10 &&
                          fused2_sub_fits((L.n + groups_n - 1) / groups_n, (L.m + groups_m - 1) / groups_m, mask != nullptr, L,
                                          ctx->lds_max);
   CatLayout Lp = L;                                // the key columns alone: the pairs-only launch
   Lp.n = 0; Lp.n_s = 0;
   const bool mfma_pairs = small_keys && (mfma_sums || !do_s) && L.m <= 10 &&
                           fused2_applicable(Lp, a->nkeys_host, mask != nullptr, ctx->lds_max);
+  // more than 10 key columns whose per-key sums the matrix-core kernel takes: the code-cache route even
+  // when every table would fit ONE launch of the LDS-atomic kernel (n x m fp64 LDS atomics per row)
+  bool wide_mfma = do_s && sums_fit && L.m > 10 && ctx->allow_fused && !ctx->no_sub;
+  for (int c = 0; c < L.m; c++) wide_mfma = wide_mfma && cat_sums_mfma_applicable(L, 1u << c, rows);
   const uint64_t piece = 1ull << 27;               // rows per code-cache fill / per sort
-  if (missed && (rows > piece || with_sparse || (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs))) {
+  if (missed && (rows > piece || with_sparse || (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs && !wide_mfma))) {
     *missed = true;                                  // (not a route the optimistic translation covers)
     return COFACTOR_OK;
   }
-  if (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs) {   // one launch does all dense tables
+  if (passes.size() == 1 && !hbm_needed && !mfma_sums && !mfma_pairs && !wide_mfma) {   // one launch does all dense tables
     {
       cofactor_status es = make_events();
       if (es != COFACTOR_OK) return es;
@@ -510,13 +517,18 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
         int nsub = 0;
         unsigned sub = 0;
         size_t used = 0;
+        // columns the matrix-core kernel takes (catsums.hip) go twelve to a launch
+        bool mfma_cols = do_s && stride % 64 == 0;
+        for (int c = 0; c < L.m; c++) mfma_cols = mfma_cols && cat_sums_mfma_applicable(L, 1u << c, trows);
+        int in_sub = 0;
         for (int c = 0; c < L.m; c++) {
           const size_t b = cat_sums_lds_bytes(L, 1u << c, do_s);
-          if (sub && used + b > ctx->lds_budget) { subs[nsub++] = sub; sub = 0; used = 0; }
-          sub |= 1u << c; used += b;
+          if (sub && (used + b > ctx->lds_budget || (mfma_cols && in_sub == 12))) { subs[nsub++] = sub; sub = 0; used = 0; in_sub = 0; }
+          sub |= 1u << c; used += b; in_sub++;
         }
         if (sub) subs[nsub++] = sub;
-        if (nsub == 1) HIP_TRY(launch_cat_sums(tn, tcodes, trows, stride, L, a->D, subs[0], ctx->cat_grid, st));
+        if (nsub == 1 || mfma_cols)
+          for (int i = 0; i < nsub; i++) HIP_TRY(launch_cat_sums(tn, tcodes, trows, stride, L, a->D, subs[i], ctx->cat_grid, st));
         else HIP_TRY(launch_cat_sums_subsets(tn, tcodes, trows, stride, L, a->D, subs, nsub, ctx->cus, st));
       } else {
         CatPass base{};

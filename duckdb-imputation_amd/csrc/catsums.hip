@@ -1,5 +1,6 @@
-// Per-key counts and per-key sums of the numeric columns for key columns of 17 .. 64 keys, on the
-// matrix cores — the code-cache route's cat_sums pass (cat.hip) without its 100 ds_add_f64 per row.
+// Per-key counts and per-key sums of the numeric columns for key columns of up to 64 keys, on the
+// matrix cores — the code-cache route's cat_sums pass (cat.hip) without its n x m ds_add_f64 per row
+// (17 .. 64 keys per column at n <= 10; <= 32 at n <= 20; the wide shapes, m > 10, at <= 16 keys).
 //
 // Replaces, for those columns, the per-row map updates of Triple::SumNoLift
 // (duckdb_extension/src/triple/sum/sum_no_lift.cpp:157-193: lin_cat[col][key] += 1,
@@ -72,6 +73,8 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
   double *l_tab = reinterpret_cast<double *>(lds_raw + 2 * 16 * NBB * CS_PST);    // [selected column][16 KB codes][n + 1]
   for (int i = tid; i < 2 * 16 * NBB * CS_PST / 2; i += CS_TW) pt0[i] = 0;
   for (int i = tid; i < nsel * KB * 16 * W1; i += CS_TW) l_tab[i] = 0.0;
+  // (a wave with fewer than CS_MC columns — or none — still issues its loads: from the first selected column)
+  const int first_col = __builtin_amdgcn_readfirstlane(l_sel[0]);
   int myc[CS_MC];
 #pragma unroll
   for (int ci = 0; ci < CS_MC; ci++) myc[ci] = __builtin_amdgcn_readfirstlane(wave + CS_NW * ci < nsel ? l_sel[wave + CS_NW * ci] : -1);
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
 
   // this thread's share of the values: row r of the tile, numeric columns j0, j0 + CS_NW, ..
   const int r = tid & 63, j0 = tid >> 6;
-  constexpr int XQ = (10 + CS_NW - 1) / CS_NW;
+  constexpr int XQ = NBB + 1;                          // numeric columns per thread: 16 NBB piece columns hold <= 5 NBB + 1
   const uint64_t ntiles = (rows + CS_TILE - 1) / CS_TILE;
   float xn[XQ];
   uint2 cn[CS_MC][2][2];                              // [column][half of the tile][8 codes as two uint2]
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
       for (int h = 0; h < 2; h++) {
         // (a column of the cache is whole 64-row tiles, CODE_NONE behind the last row: no clamping here)
         const unsigned off = 32u * h + 8u * g;
-        const unsigned short *col = codes + (uint64_t)(myc[ci] >= 0 ? myc[ci] : myc[0]) * stride + row0;
+        const unsigned short *col = codes + (uint64_t)(myc[ci] >= 0 ? myc[ci] : first_col) * stride + row0;
         const uint4 v = *reinterpret_cast<const uint4 *>(col + off);
         cn[ci][h][0] = make_uint2(v.x, v.y);
         cn[ci][h][1] = make_uint2(v.z, v.w);
@@ -227,13 +230,15 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
 
 }  // namespace
 
-// columns of col_mask: all between 1 and 64 codes, at most 12 of them, 1 <= n <= 10, triple kind
+// columns of col_mask: at most 64 codes each, at most 12 of them, triple kind, 1 <= n <= 20, and code
+// blocks x piece blocks <= 8 (96 accumulator registers per wave)
 bool cat_sums_mfma_applicable(const CatLayout &L, unsigned col_mask, uint64_t rows) {
-  if (L.kind != 0 || L.n < 1 || 3 * L.n + 1 > 32 || rows < 4096) return false;
+  if (L.kind != 0 || L.n < 1 || 3 * L.n + 1 > 64 || rows < 4096) return false;
   int nsel = 0, kmax = 0;
   for (int c = 0; c < L.m; c++)
     if ((col_mask >> c) & 1u) { nsel++; kmax = std::max(kmax, L.kc[c]); }
-  return nsel >= 1 && nsel <= CS_NW * CS_MC && kmax > 16 && kmax <= 64;
+  const int KB = (kmax + 15) / 16, NBB = (3 * L.n + 1 + 15) / 16;
+  return nsel >= 1 && nsel <= CS_NW * CS_MC && kmax >= 1 && kmax <= 64 && KB * NBB <= 8;
 }
 
 hipError_t launch_cat_sums_mfma(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
@@ -254,7 +259,8 @@ hipError_t launch_cat_sums_mfma(const NumCols &num, const unsigned short *codes,
                        L, D, col_mask);                                                                            \
     return hipGetLastError();                                                                                      \
   }
-  CS_CASE(2, 1) CS_CASE(2, 2) CS_CASE(3, 1) CS_CASE(3, 2) CS_CASE(4, 1) CS_CASE(4, 2)
+  CS_CASE(1, 1) CS_CASE(1, 2) CS_CASE(1, 3) CS_CASE(1, 4) CS_CASE(2, 1) CS_CASE(2, 2) CS_CASE(2, 3) CS_CASE(2, 4)
+  CS_CASE(3, 1) CS_CASE(3, 2) CS_CASE(4, 1) CS_CASE(4, 2)
 #undef CS_CASE
   return hipErrorInvalidValue;
 }
