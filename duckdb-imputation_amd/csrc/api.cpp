@@ -520,10 +520,12 @@ cofactor_status cat_accumulate(cofactor_agg *a, const NumCols &num, const CatCol
         // columns the matrix-core kernel takes (catsums.hip) go twelve to a launch
         bool mfma_cols = do_s && stride % 64 == 0;
         for (int c = 0; c < L.m; c++) mfma_cols = mfma_cols && cat_sums_mfma_applicable(L, 1u << c, trows);
+        bool all_small = true;                       // <= 16 codes everywhere: up to 24 columns a launch (eight waves)
+        for (int c = 0; c < L.m; c++) all_small = all_small && L.kc[c] <= 16;
         int in_sub = 0;
         for (int c = 0; c < L.m; c++) {
           const size_t b = cat_sums_lds_bytes(L, 1u << c, do_s);
-          if (sub && (used + b > ctx->lds_budget || (mfma_cols && in_sub == 12))) { subs[nsub++] = sub; sub = 0; used = 0; in_sub = 0; }
+          if (sub && (used + b > ctx->lds_budget || (mfma_cols && in_sub == (all_small ? 24 : 12)))) { subs[nsub++] = sub; sub = 0; used = 0; in_sub = 0; }
           sub |= 1u << c; used += b; in_sub++;
         }
         if (sub) subs[nsub++] = sub;

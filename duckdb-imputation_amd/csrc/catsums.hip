@@ -32,9 +32,9 @@ namespace {
 constexpr int CS_TILE = 64;
 constexpr int CS_PST = 144;           // bytes of one piece column in LDS: 64 rows bf16 + 16 (bank spread)
 constexpr int CS_FOLD_TILES = 32;
-constexpr int CS_TW = 256;            // threads: four waves share a tile's key columns (eight waves with two
-constexpr int CS_NW = CS_TW / 64;     // columns each: 15 % slower, the two barriers per tile cost more)
 constexpr int CS_MC = 3;              // key columns per wave
+// CS_TW threads (template parameter): four waves share a tile's key columns, eight when there are more
+// than twelve of them (wide shapes: one split of the numeric values into pieces serves all key columns)
 
 // 8 u16 codes (two uint2) -> 8 bf16 one-hot values for code `ii` (in both halves): d = code ^ ii is 0
 // only on a match; min(d, 1) is 0 / 1; 0x3F80 + min * 0xC080 (mod 2^16) is bf16 1.0 or 0.
@@ -52,9 +52,10 @@ __device__ __forceinline__ cs_bf16x8 cs_onehot8(uint2 lo, uint2 hi, unsigned ii)
   return __builtin_bit_cast(cs_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
 }
 
-template <int KB, int NBB>
-__global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, const unsigned short *__restrict__ codes, uint64_t rows,
+template <int KB, int NBB, int CS_TW>
+__global__ __launch_bounds__(CS_TW, CS_TW == 256 ? 2 : 1) void cat_sums_mfma_kernel(NumCols num, const unsigned short *__restrict__ codes, uint64_t rows,
                                                             uint64_t stride, CatLayout L, CatDevice D, unsigned col_mask) {
+  constexpr int CS_NW = CS_TW / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int l_sel[COFACTOR_MAX_CAT];
   __shared__ int l_nsel;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(CS_TW, 2) void cat_sums_mfma_kernel(NumCols num, co
 
   // this thread's share of the values: row r of the tile, numeric columns j0, j0 + CS_NW, ..
   const int r = tid & 63, j0 = tid >> 6;
-  constexpr int XQ = NBB + 1;                          // numeric columns per thread: 16 NBB piece columns hold <= 5 NBB + 1
+  constexpr int XQ = (5 * NBB + 1 + CS_NW - 1) / CS_NW;   // numeric columns per thread: 16 NBB piece columns hold <= 5 NBB + 1
   const uint64_t ntiles = (rows + CS_TILE - 1) / CS_TILE;
   float xn[XQ];
   uint2 cn[CS_MC][2][2];                              // [column][half of the tile][8 codes as two uint2]
@@ -238,7 +239,7 @@ bool cat_sums_mfma_applicable(const CatLayout &L, unsigned col_mask, uint64_t ro
   for (int c = 0; c < L.m; c++)
     if ((col_mask >> c) & 1u) { nsel++; kmax = std::max(kmax, L.kc[c]); }
   const int KB = (kmax + 15) / 16, NBB = (3 * L.n + 1 + 15) / 16;
-  return nsel >= 1 && nsel <= CS_NW * CS_MC && kmax >= 1 && kmax <= 64 && KB * NBB <= 8;
+  return nsel >= 1 && nsel <= 8 * CS_MC && kmax >= 1 && kmax <= 64 && KB * NBB <= 8 && (nsel <= 4 * CS_MC || KB == 1);
 }
 
 hipError_t launch_cat_sums_mfma(const NumCols &num, const unsigned short *codes, uint64_t rows, uint64_t stride,
@@ -249,18 +250,20 @@ hipError_t launch_cat_sums_mfma(const NumCols &num, const unsigned short *codes,
   const int KB = (kmax + 15) / 16, NBB = (3 * L.n + 1 + 15) / 16;
   const size_t lds = (size_t)2 * 16 * NBB * CS_PST + (size_t)nsel * KB * 16 * (L.n + 1) * 8;
   const uint64_t ntiles = (rows + CS_TILE - 1) / CS_TILE;
-  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)std::max(wgs, 1));
-#define CS_CASE(K, B)                                                                                              \
-  if (KB == K && NBB == B) {                                                                                       \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cat_sums_mfma_kernel<K, B>),                 \
+  const int TW = nsel > 4 * CS_MC ? 512 : 256;         // (512: one workgroup per CU)
+  const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, (uint64_t)std::max(TW == 512 ? wgs / 2 : wgs, 1));
+#define CS_CASE(K, B, T)                                                                                           \
+  if (KB == K && NBB == B && TW == T) {                                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cat_sums_mfma_kernel<K, B, T>),              \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
     if (e != hipSuccess) return e;                                                                                 \
-    hipLaunchKernelGGL((cat_sums_mfma_kernel<K, B>), dim3(grid), dim3(CS_TW), lds, stream, num, codes, rows, stride, \
+    hipLaunchKernelGGL((cat_sums_mfma_kernel<K, B, T>), dim3(grid), dim3(T), lds, stream, num, codes, rows, stride, \
                        L, D, col_mask);                                                                            \
     return hipGetLastError();                                                                                      \
   }
-  CS_CASE(1, 1) CS_CASE(1, 2) CS_CASE(1, 3) CS_CASE(1, 4) CS_CASE(2, 1) CS_CASE(2, 2) CS_CASE(2, 3) CS_CASE(2, 4)
-  CS_CASE(3, 1) CS_CASE(3, 2) CS_CASE(4, 1) CS_CASE(4, 2)
+  CS_CASE(1, 1, 256) CS_CASE(1, 2, 256) CS_CASE(1, 3, 256) CS_CASE(1, 4, 256) CS_CASE(2, 1, 256) CS_CASE(2, 2, 256)
+  CS_CASE(2, 3, 256) CS_CASE(2, 4, 256) CS_CASE(3, 1, 256) CS_CASE(3, 2, 256) CS_CASE(4, 1, 256) CS_CASE(4, 2, 256)
+  CS_CASE(1, 1, 512) CS_CASE(1, 2, 512) CS_CASE(1, 3, 512) CS_CASE(1, 4, 512)
 #undef CS_CASE
   return hipErrorInvalidValue;
 }

@@ -23,6 +23,10 @@ if [ "$2" = "k64" ]; then
   run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && run 10_10_k32 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 32 && echo k64 collected
   exit 0
 fi
+if [ "$2" = "wide" ]; then
+  run 20_20 --total-rows 5e7 --num-cols 20 --cat-cols 20 && echo wide collected
+  exit 0
+fi
 if [ "$2" = "rest" ]; then
   run 10_10_k64 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 64 && run 20_20 --total-rows 5e7 --num-cols 20 --cat-cols 20 \
     && run 10_10_k1000 --total-rows 5e7 --num-cols 10 --cat-cols 10 --keys 1000 && echo rest collected
