@@ -208,7 +208,7 @@ __global__ __launch_bounds__(CS_TW, CS_TW == 256 ? 2 : 1) void cat_sums_mfma_ker
 #pragma unroll
           for (int bb = 0; bb < NBB; bb++) acc[ci][kb][bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bop[h][bb], acc[ci][kb][bb], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);             // one block's one-hots at a time: hoisting them all costs 100 registers
+        if (KB * NBB > 4) __builtin_amdgcn_sched_barrier(0);   // one block's one-hots at a time: hoisting them all costs 100 registers
       }
     }
     if (++since == CS_FOLD_TILES) { fold(); since = 0; }
