@@ -34,7 +34,7 @@ SYMBOLS = [
     "cofactor_lift_device", "cofactor_agg_update_tvec_device", "cofactor_multiply_device",
     "cofactor_lift_host_tvec", "cofactor_agg_update_tvec_host", "cofactor_multiply_host",
     "cofactor_groups_create", "cofactor_groups_destroy", "cofactor_groups_update_device",
-    "cofactor_groups_update_host", "cofactor_groups_count", "cofactor_groups_combine",
+    "cofactor_groups_update_host", "cofactor_groups_count", "cofactor_groups_combine", "cofactor_groups_reset_group",
     "cofactor_groups_finalize", "cofactor_groups_to_tvec",
     "cofactor_blob_len", "cofactor_triple_to_text", "cofactor_triple_from_text",
     "cofactor_linreg_train", "cofactor_lda_train",

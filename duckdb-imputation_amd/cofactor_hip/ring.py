@@ -45,6 +45,7 @@ def _bind():
     L.cofactor_groups_update_host.argtypes = [_vp, _vp, pp, pp, _u64]
     L.cofactor_groups_count.argtypes = [_vp, pu]
     L.cofactor_groups_combine.argtypes = [_vp, _i32, _i32]
+    L.cofactor_groups_reset_group.argtypes = [_vp, _i32]
     L.cofactor_groups_finalize.argtypes = [_vp, _i32, _vp, _u64, pu]
     L.cofactor_groups_to_tvec.argtypes = [_vp, pt, _vp, pu, pu, pu]
     L._ring_bound = True
@@ -289,6 +290,9 @@ class Groups:
 
     def combine(self, dst, src):
         _check(_bind().cofactor_groups_combine(self._h, dst, src))
+
+    def reset_group(self, gid):
+        _check(_bind().cofactor_groups_reset_group(self._h, gid))
 
     def finalize(self, gid):
         L = _bind()

@@ -810,6 +810,18 @@ cofactor_status cofactor_groups_combine(cofactor_groups *g, int32_t dst_gid, int
   return COFACTOR_OK;
 }
 
+cofactor_status cofactor_groups_reset_group(cofactor_groups *g, int32_t gid) {
+  if (!g) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (g->is_key || gid < 0) return fail(COFACTOR_ERR_INVALID, "reset_group: slot-id pools only, slot >= 0");
+  CTX_LOCK(g->ctx);
+  DeviceGuard guard(g->ctx->device);
+  cofactor_status s = groups_flush(g);               // rows handed over for the slot's previous owner go in first
+  if (s != COFACTOR_OK) return s;
+  if (gid >= g->groups) return COFACTOR_OK;          // (no row yet: nothing to clear)
+  HIP_TRY(hipMemsetAsync(g->tab + (long long)gid * g->dtot, 0, sizeof(double) * (size_t)g->dtot, g->ctx->stream));
+  return COFACTOR_OK;
+}
+
 cofactor_status cofactor_groups_finalize(cofactor_groups *g, int32_t gid, double *out, uint64_t cap, uint64_t *needed) {
   if (!g) return fail(COFACTOR_ERR_INVALID, "null argument");
   CTX_LOCK(g->ctx);

@@ -102,6 +102,7 @@ struct GroupPool {
   std::mutex mu;
   cofactor_groups *grp = nullptr;
   int32_t next_slot = 0;
+  std::vector<int32_t> free_slots;                    // slots of destroyed states, cleared when handed out again
   ~GroupPool() { cofactor_groups_destroy(grp); }
 };
 
@@ -134,9 +135,21 @@ struct RingStateFunction {
   template <class STATE>
   static void Initialize(STATE &state) { state.agg = nullptr; state.pool = nullptr; state.slot = -1; }
   template <class STATE>
-  static void Destroy(STATE &state, AggregateInputData &) {
-    cofactor_agg_destroy(state.agg);                  // (a slot lives and dies with the query's pool)
+  static void Destroy(STATE &state, AggregateInputData &aid) {
+    cofactor_agg_destroy(state.agg);
     state.agg = nullptr;
+    // the slot goes back to its pool (reached through the bind data, which outlives the states): a
+    // prepared statement that runs again, or thread-local states that were combined away, would
+    // otherwise only ever add rows to the pool's table
+    if (state.slot >= 0 && aid.bind_data) {
+      auto &pool = aid.bind_data->template Cast<RingBindData>().pool;
+      if (pool && pool.get() == state.pool) {
+        std::lock_guard<std::mutex> lock(pool->mu);
+        pool->free_slots.push_back(state.slot);
+      }
+    }
+    state.slot = -1;
+    state.pool = nullptr;
   }
   static bool IgnoreNull() { return false; }
 };
@@ -331,7 +344,16 @@ static void RingUpdate(Vector inputs[], AggregateInputData &aggr, idx_t cols, Ve
     for (idx_t i = 0; i < count; i++) {
       RingState *st = states[sdata.sel->get_index(i)];
       if (st->agg && st->slot < 0) { rows_of[st].push_back((uint32_t)i); continue; }
-      if (st->slot < 0) { st->slot = pool->next_slot++; st->pool = pool; }
+      if (st->slot < 0) {
+        if (!pool->free_slots.empty()) {              // a destroyed state's slot, cleared first
+          st->slot = pool->free_slots.back();
+          pool->free_slots.pop_back();
+          Check(cofactor_groups_reset_group(pool->grp, st->slot));
+        } else {
+          st->slot = pool->next_slot++;
+        }
+        st->pool = pool;
+      }
       if (st->pool != pool) throw InvalidInputException("duckdb_imputation: aggregate state used with a foreign group pool");
       gid.push_back(st->slot);
       pooled.push_back((uint32_t)i);

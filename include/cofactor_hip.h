@@ -408,6 +408,10 @@ cofactor_status cofactor_groups_update_host(cofactor_groups *grp, const int32_t 
                                             uint64_t rows);
 cofactor_status cofactor_groups_count(cofactor_groups *grp, uint64_t *n_groups);
 cofactor_status cofactor_groups_combine(cofactor_groups *grp, int32_t dst_gid, int32_t src_gid);
+/* slot-id pools (is_key = 0): group `gid` back to the empty triple, so that the slot of a state DuckDB
+ * has destroyed (after its combine / finalize) can serve the next new group — without it a prepared
+ * statement executed again and again only ever grows its table. */
+cofactor_status cofactor_groups_reset_group(cofactor_groups *grp, int32_t gid);
 cofactor_status cofactor_groups_finalize(cofactor_groups *grp, int32_t gid, double *out,
                                          uint64_t cap, uint64_t *needed);
 cofactor_status cofactor_groups_to_tvec(cofactor_groups *grp, cofactor_tvec *out,

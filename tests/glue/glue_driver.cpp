@@ -119,11 +119,13 @@ struct AggRun {
     fn.finalize(states, aid, result, state_mem.size(), 0);
     return result;
   }
-  ~AggRun() {
+  void DestroyStates() {                        // what DuckDB does with a hash table's states when the query ends
     Vector states(LogicalType(LogicalType::ANY), 64);
     for (size_t g = 0; g < state_mem.size(); g++) FlatVector::GetData<data_ptr_t>(states)[g] = state_mem[g].data();
     if (fn.destructor) fn.destructor(states, aid, state_mem.size());
+    state_mem.clear();
   }
+  ~AggRun() { DestroyStates(); }
 };
 
 static std::vector<Vector> Cols(const std::string &names, const std::vector<int> &rows, bool dict) {
@@ -185,6 +187,28 @@ int main() {
         run.Update(c2, {1, 1});
         Vector r = run.Finalize();
         out << ",\"" << pfx << "sum_group_by\":" << Rows(r, 2);
+      }
+      {  // a prepared statement executed twice: the same bind data (and GROUP BY pool), fresh states; the
+         // states of the first execution are destroyed, their pool slots handed out again — cleared
+        AggRun first(fn33, 2);
+        std::shared_ptr<FunctionData> bind = first.bind_data;
+        auto c1 = Cols("abcdef", {0, 1, 2}, true);
+        auto c2 = Cols("abcdef", {3, 4}, true);
+        {
+          AggRun local(fn33, 2, bind);                 // a thread-local run combined into `first` and destroyed
+          local.Update(c1, {0, 0, 1});
+          local.CombineInto(first);
+        }
+        first.Update(c2, {1, 1});
+        Vector r1 = first.Finalize();
+        std::string once = Rows(r1, 2);
+        first.DestroyStates();
+        AggRun again(fn33, 2, bind);
+        again.Update(c1, {0, 0, 1});
+        again.Update(c2, {1, 1});
+        Vector r2 = again.Finalize();
+        if (Rows(r2, 2) != once) throw std::runtime_error("second execution on the same pool differs from the first");
+        out << ",\"" << pfx << "sum_group_by_executed_twice\":" << Rows(r2, 2);
       }
       {  // two worker threads' local states combined into global ones (one of them empty for group 0)
         AggRun global(fn33, 2);

@@ -45,6 +45,7 @@ def test_glue_callbacks_reproduce_reference_goldens(goldens, ref_table):
         assert doc[pfx + "sum_all"] == _expected(goldens, fname, 0)
         grouped = _expected(goldens, fname, 1)
         assert doc[pfx + "sum_group_by"] == grouped          # dictionary vectors, two chunks
+        assert doc[pfx + "sum_group_by_executed_twice"] == grouped    # recycled pool slots are cleared
         assert doc[pfx + "sum_combined"] == grouped          # thread-local states combined
         assert doc[pfx + "sum_combined_copied_bind"] == grouped   # ... through a Copy() of the bind data (shared pool)
         assert doc[pfx + "sum_two_contexts"] == _expected(goldens, fname, 0)   # two threads, two contexts, combine

@@ -304,6 +304,32 @@ def test_group_by_pool_collects_host_chunks_before_it_goes_to_the_device(ctx, n,
     grp.close()
 
 
+def test_group_by_pool_slot_is_cleared_for_its_next_owner(ctx):
+    """cofactor_groups_reset_group: rows staged for the slot's previous owner still go in before the row
+    is cleared; the next owner starts from the empty triple; other slots are untouched; key-typed pools
+    refuse."""
+    rng = np.random.default_rng(4)
+    n, m, rows = 3, 1, 5000
+    slot = rng.integers(0, 4, rows).astype(np.int32)
+    num = [rng.integers(0, 16, rows).astype(np.float32) for _ in range(n)]
+    cat = [rng.integers(0, 5, rows).astype(np.int32) for _ in range(m)]
+    grp = ring.Groups(ctx, n, m, cofactor_hip.TRIPLE, is_key=False)
+    grp.update_host(slot, num, cat)                  # (staged in pinned memory)
+    grp.reset_group(2)
+    want = orc.grouped_update(num, cat, slot, 4, nb=False)
+    assert blob_to_dict(grp.finalize(1)) == blob_to_dict(want[1].finalize())
+    assert blob_to_dict(grp.finalize(2))["N"] == 0
+    sel = slot == 0
+    grp.update_host(np.full(int(sel.sum()), 2, np.int32), [c[sel] for c in num], [c[sel] for c in cat])
+    assert blob_to_dict(grp.finalize(2)) == blob_to_dict(want[0].finalize())
+    grp.reset_group(7)                               # (no such row yet: nothing to do)
+    grp.close()
+    keyed = ring.Groups(ctx, n, m, cofactor_hip.TRIPLE, is_key=True)
+    with pytest.raises(cofactor_hip.CofactorError):
+        keyed.reset_group(0)
+    keyed.close()
+
+
 def _join_tables(G, per, seed):
     rng = np.random.default_rng(seed)
     rows = G * per
