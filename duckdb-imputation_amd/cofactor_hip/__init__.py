@@ -34,7 +34,7 @@ SYMBOLS = [
     "cofactor_lift_device", "cofactor_agg_update_tvec_device", "cofactor_multiply_device",
     "cofactor_lift_host_tvec", "cofactor_agg_update_tvec_host", "cofactor_multiply_host",
     "cofactor_groups_create", "cofactor_groups_destroy", "cofactor_groups_update_device",
-    "cofactor_groups_update_host", "cofactor_groups_count", "cofactor_groups_combine", "cofactor_groups_reset_group",
+    "cofactor_groups_update_host", "cofactor_groups_count", "cofactor_groups_combine", "cofactor_groups_reset_group", "cofactor_linreg_predict_rows_device",
     "cofactor_groups_finalize", "cofactor_groups_to_tvec",
     "cofactor_blob_len", "cofactor_triple_to_text", "cofactor_triple_from_text",
     "cofactor_linreg_train", "cofactor_lda_train",
@@ -119,6 +119,7 @@ def lib():
         L.cofactor_linreg_train.argtypes = [vp, u64, i32, f32, f32, i32, i32, i32, vp, u64, pu64]
         L.cofactor_lda_train.argtypes = [vp, u64, i32, f32, i32, vp, u64, pu64]
         L.cofactor_linreg_predict_device.argtypes = [vp, vp, u64, i32, i32, u64, pp, i32, pp, i32, vp, u64, vp]
+        L.cofactor_linreg_predict_rows_device.argtypes = [vp, vp, u64, i32, i32, u64, pp, i32, pp, i32, vp, vp, u64, vp]
         L.cofactor_lda_predict_device.argtypes = [vp, vp, u64, i32, i32, pp, i32, pp, i32, vp, u64, vp]
         L.cofactor_linreg_predict_host.argtypes = [vp, vp, u64, i32, i32, u64, pp, i32, pp, i32, u64, vp]
         L.cofactor_lda_predict_host.argtypes = [vp, vp, u64, i32, i32, pp, i32, pp, i32, u64, vp]
@@ -196,7 +197,7 @@ class Context:
 
     # ---- per-row predictors over device columns (torch tensors) or host columns (numpy) ----
     def linreg_predict(self, params, num_cols, cat_cols, out=None, mask=None, noise=False,
-                       normalize=False, seed=0):
+                       normalize=False, seed=0, row_ids=None):
         """linreg_predict(params, noise, normalize, feature columns.., key columns..): device
         tensors write `out` (float32 device tensor; only rows with mask != 0 when a mask is
         given), numpy columns return a new float32 array."""
@@ -206,6 +207,14 @@ class Context:
             _check_cols(num_cols, cat_cols, rows, mask)
             assert str(out.dtype) == "torch.float32" and out.is_cuda and out.is_contiguous()
             _torch_handover([out])
+            if row_ids is not None:                  # (uint32 device tensor: the rows' original places)
+                assert row_ids.is_cuda and row_ids.is_contiguous() and row_ids.numel() == rows and row_ids.element_size() == 4
+                _check(lib().cofactor_linreg_predict_rows_device(
+                    self._h, prm.ctypes.data, prm.size, int(noise), int(normalize), seed,
+                    _ptr_array([t.data_ptr() for t in num_cols]), len(num_cols),
+                    _ptr_array([t.data_ptr() for t in cat_cols]), len(cat_cols),
+                    None if mask is None else mask.data_ptr(), row_ids.data_ptr(), rows, out.data_ptr()))
+                return out
             _check(lib().cofactor_linreg_predict_device(
                 self._h, prm.ctypes.data, prm.size, int(noise), int(normalize), seed,
                 _ptr_array([t.data_ptr() for t in num_cols]), len(num_cols),
@@ -475,9 +484,17 @@ def lift_host(num_cols, cat_cols, kind=TRIPLE):
     return [out[int(offs[i]):int(offs[i + 1])].copy() for i in range(rows)]
 
 
-def _binary(fn, a, b):
+def _binary(fn, a, b, bound=None):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
+    if bound is not None:                             # a buffer that surely holds the result: ONE call
+        need = C.c_uint64(0)
+        out = np.empty(bound, dtype=np.float64)
+        st = fn(a.ctypes.data, a.size, b.ctypes.data, b.size, out.ctypes.data, out.size, C.byref(need))
+        if st == OK:
+            return out[:need.value].copy()
+        if st != ERR_CAPACITY:
+            _check(st)
     return _two_call(fn, a.ctypes.data, a.size, b.ctypes.data, b.size)
 
 
@@ -486,11 +503,11 @@ def multiply(a, b):
 
 
 def add(a, b):
-    return _binary(lib().cofactor_triple_add, a, b)
+    return _binary(lib().cofactor_triple_add, a, b, bound=len(a) + len(b))
 
 
 def sub(a, b):
-    return _binary(lib().cofactor_triple_sub, a, b)
+    return _binary(lib().cofactor_triple_sub, a, b, bound=len(a) + len(b))
 
 
 def _two_call_f32(fn, *args):

@@ -123,3 +123,156 @@ def run_mice(ctx, table, iterations=1, dist=None, device=None, seed=0, shrinkage
                 t_log["predict_s"] += t3 - t2
     agg.close()
     return models
+
+
+# ---- the partitioned variant ---------------------------------------------------------------------------
+# imputation/algorithms/imputation_low.cpp / imputation_high.cpp keep the table PARTITIONED by its null
+# pattern, so that "the rows where col is missing" are whole partitions, and keep one cofactor of the
+# whole table up to date instead of aggregating it again for every column:
+#     triple(rows where col is present) = triple(all rows) - triple(rows where col is missing)
+# Per column that is two aggregates over the ~10 % of rows where it is missing (before and after the
+# imputation), contiguous row ranges of the reordered table — no row filter, nothing read of the rows
+# without a missing value.
+
+def _gray_rank(p):
+    """Place of bit pattern p in the reflected Gray sequence: patterns are laid out in that order, so
+    the partitions where a given column is missing form one or two runs instead of up to 2^(k-1)."""
+    b = p
+    shift = 1
+    while (p >> shift) > 0:
+        b ^= p >> shift
+        shift += 1
+    return b
+
+
+class PartitionedMiceTable:
+    """A MiceTable's rows reordered by null pattern (stable within a pattern).  `ranges[name]` are the
+    row ranges [a, b) of the reordered columns in which `name` is missing; `row_ids` the rows' places
+    in the original shard (the imputation noise is a function of those)."""
+
+    def __init__(self, table):
+        import torch
+        self.source = table
+        self.names = list(table.cat_null) + list(table.num_null)          # processing order = bit order
+        k = len(self.names)
+        assert 1 <= k <= 8
+        nulls = [table.cat_null[c] if c in table.cat_null else table.num_null[c] for c in self.names]
+        rows = nulls[0].numel()
+        pat = torch.zeros(rows, dtype=torch.int32, device=nulls[0].device)
+        for b, nl in enumerate(nulls):
+            pat += (nl != 0).to(torch.int32) << b
+        rank_of = torch.tensor([_gray_rank(p) for p in range(1 << k)], dtype=torch.int32, device=pat.device)
+        rank = rank_of[pat.long()]
+        order = torch.argsort(rank, stable=True)
+        self.order = order
+        self.row_ids = order.to(torch.int32).contiguous()                  # (< 2^31 rows per shard; read as uint32)
+        self.num = {c: v[order].contiguous() for c, v in table.num.items()}
+        self.cat = {c: v[order].contiguous() for c, v in table.cat.items()}
+        counts = torch.bincount(rank.long(), minlength=1 << k).cpu().numpy()
+        start = np.concatenate([[0], np.cumsum(counts)])
+        pattern_at = [0] * (1 << k)
+        for p in range(1 << k):
+            pattern_at[_gray_rank(p)] = p
+        self.ranges = {}
+        for b, name in enumerate(self.names):
+            runs = []
+            for r in range(1 << k):
+                if (pattern_at[r] >> b) & 1 and counts[r] > 0:
+                    a, e = int(start[r]), int(start[r + 1])
+                    if runs and runs[-1][1] == a:
+                        runs[-1] = (runs[-1][0], e)
+                    else:
+                        runs.append((a, e))
+            self.ranges[name] = runs
+        torch.cuda.synchronize()
+
+    def write_back(self):
+        """The imputed columns back into the source table's row order."""
+        import torch
+        for name in self.names:
+            src = self.cat[name] if name in self.cat and name in self.source.cat_null else self.num[name]
+            dst = self.source.cat[name] if name in self.source.cat_null else self.source.num[name]
+            dst[self.order] = src
+        torch.cuda.synchronize()
+
+
+def _aggregate_ranges(agg, cols_num, cols_cat, ranges):
+    """agg += the rows of the ranges.  A range that does not start on a multiple of four rows is fed in
+    two pieces (the library's fast kernels want 16-byte aligned columns)."""
+    for a, b in ranges:
+        head = min(b, (a + 3) // 4 * 4)
+        for lo, hi in ((a, head), (head, b)):
+            if hi > lo:
+                agg.update_device_ptrs([t.data_ptr() + 4 * lo for t in cols_num], [t.data_ptr() + 4 * lo for t in cols_cat], hi - lo)
+
+
+def run_mice_partitioned(ctx, table, iterations=1, dist=None, device=None, seed=0, shrinkage=0.001,
+                         step_size=0.001, max_iterations=10000, timings=None, skip_init=False, part=None):
+    """run_mice over the table partitioned by null pattern.  Same models and — to the rounding of one
+    blob subtraction — the same imputed values as run_mice; returns (models, partitioned table).  The
+    source table is written when `part.write_back()` is called."""
+    import torch
+    from . import add as triple_add
+    from . import sub as triple_sub
+    num_names, cat_names = list(table.num), list(table.cat)
+    n, m = len(num_names), len(cat_names)
+    t_log = timings if timings is not None else {}
+    for k in ("aggregate_s", "train_s", "predict_s", "partition_s"):
+        t_log.setdefault(k, 0.0)
+
+    def clock():
+        torch.cuda.synchronize(device)
+        return time.perf_counter()
+
+    if not skip_init and part is None:
+        init_baseline(ctx, table, dist, device)
+    t0 = clock()
+    pt = part if part is not None else PartitionedMiceTable(table)
+    cols_num = [pt.num[c] for c in num_names]
+    cols_cat = [pt.cat[c] for c in cat_names]
+    agg = ctx.aggregate(n, m)
+    if getattr(pt, "total", None) is None:
+        agg.update_device(cols_num, cols_cat)                    # the cofactor of the whole (filled) table, once
+        pt.total = _reduced_triple(agg, dist, device)
+    t_log["partition_s"] += clock() - t0
+    models = {}
+    for it in range(iterations):
+        for name in pt.names:
+            kind = "cat" if name in table.cat_null else "num"
+            ranges = pt.ranges[name]
+            t0 = clock()
+            agg.reset()
+            _aggregate_ranges(agg, cols_num, cols_cat, ranges)
+            old = _reduced_triple(agg, dist, device)
+            triple = triple_sub(pt.total, old)                   # the rows where `name` is present
+            t1 = clock()
+            if kind == "cat":
+                label = cat_names.index(name)
+                params = lda_train(triple, label, shrinkage, False)
+                t2 = clock()
+                for a, b in ranges:
+                    ctx.lda_predict(params, [t[a:b] for t in cols_num],
+                                    [pt.cat[c][a:b] for c in cat_names if c != name],
+                                    out=pt.cat[name][a:b], mask=None, emit_label=True)
+            else:
+                label = num_names.index(name)
+                params = linreg_train(triple, label, step_size, 0.0, max_iterations, True, False)
+                t2 = clock()
+                col_seed = (seed * 1000003 + it * 10007 + label * 101 + 1) & (2 ** 63 - 1)
+                col_seed = (col_seed + 0x9E3779B97F4A7C15 * table.first_row) & (2 ** 64 - 1)
+                for a, b in ranges:
+                    ctx.linreg_predict(params, [pt.num[c][a:b] for c in num_names if c != name],
+                                       [t[a:b] for t in cols_cat], out=pt.num[name][a:b], mask=None,
+                                       noise=True, seed=col_seed, row_ids=pt.row_ids[a:b])
+            t3 = clock()
+            agg.reset()
+            _aggregate_ranges(agg, cols_num, cols_cat, ranges)
+            new = _reduced_triple(agg, dist, device)
+            pt.total = triple_add(triple, new)
+            t4 = clock()
+            models[name] = params
+            t_log["aggregate_s"] += (t1 - t0) + (t4 - t3)
+            t_log["train_s"] += t2 - t1
+            t_log["predict_s"] += t3 - t2
+    agg.close()
+    return models, pt

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -2307,9 +2308,49 @@ cofactor_status cofactor_triple_multiply(const double *a, uint64_t a_len, const 
   return emit_blob(blob, out, cap, needed);
 }
 
+// a +- b on the flat blobs when both hold exactly the same (ascending) key lists — what a MICE loop
+// adds and subtracts (the cofactor of the table and of some of its rows): no decode into lists, no
+// std::map per list, no encode.  false: the structures differ (or are malformed): the general path decides.
+static bool add_sub_flat(const double *a, const double *b, uint64_t len, bool sub, std::vector<double> &r) {
+  if (len < 4 || a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) return false;
+  const double kind = a[0], nd = a[1], md = a[2];
+  if ((kind != 0 && kind != 1) || nd < 0 || md < 0 || nd > 64 || md > 64 || nd != std::floor(nd) || md != std::floor(md)) return false;
+  const uint64_t n = (uint64_t)nd, m = (uint64_t)md;
+  const double sgn = sub ? -1.0 : 1.0;
+  r.resize(len);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+  uint64_t p = 3;
+  const uint64_t dense = 1 + n + (kind ? n : n * (n + 1) / 2);
+  if (p + dense > len) return false;
+  for (uint64_t i = 0; i < dense; i++, p++) r[p] = a[p] + sgn * b[p];
+  auto lists = [&](uint64_t count, uint64_t width) {   // width: key words per entry
+    for (uint64_t l = 0; l < count; l++) {
+      if (p >= len || a[p] != b[p] || a[p] < 0 || a[p] != std::floor(a[p])) return false;
+      const uint64_t ln = (uint64_t)a[p];
+      r[p] = a[p]; p++;
+      if (ln > (len - p) / (width + 1)) return false;
+      for (uint64_t e = 0; e < ln; e++) {
+        for (uint64_t w = 0; w < width; w++, p++) { if (a[p] != b[p]) return false; r[p] = a[p]; }
+        if (e && !(a[p - width - (width + 1)] < a[p - width] ||
+                   (width == 2 && a[p - width - (width + 1)] == a[p - width] && a[p - width + 1 - (width + 1)] < a[p - width + 1])))
+          return false;                               // (not ascending: the general path sorts)
+        r[p] = a[p] + sgn * b[p]; p++;
+      }
+    }
+    return true;
+  };
+  if (!lists(m, 1)) return false;
+  if (!kind && (!lists(n * m, 1) || !lists(m * (m + 1) / 2, 2))) return false;
+  return p == len;
+}
+
 static cofactor_status add_sub_impl(const double *a, uint64_t a_len, const double *b, uint64_t b_len, bool sub,
                                     double *out, uint64_t cap, uint64_t *needed) {
   if (!a || !b) return fail(COFACTOR_ERR_INVALID, "null argument");
+  if (a_len == b_len) {
+    std::vector<double> flat;
+    if (add_sub_flat(a, b, a_len, sub, flat)) { g_err.clear(); return emit_blob(flat, out, cap, needed); }
+  }
   ListTriple A, B, R;
   std::string err, warn;
   if (!blob_decode(a, a_len, A, err) || !blob_decode(b, b_len, B, err)) return fail(COFACTOR_ERR_INVALID, err);
@@ -2437,7 +2478,7 @@ static cofactor_status predict_device(cofactor_ctx *ctx, const PredictModel &mdl
                                       bool emit_label, bool noise, uint64_t seed,
                                       const float *const *d_num, const int32_t *const *d_cat,
                                       const uint8_t *d_mask, uint64_t rows, float *out_f,
-                                      int32_t *out_i) {
+                                      int32_t *out_i, const uint32_t *d_row_ids = nullptr) {
   if (mdl.F > COFACTOR_MAX_NUM || mdl.M > COFACTOR_MAX_CAT)
     return fail(COFACTOR_ERR_UNSUPPORTED, "too many columns");
   if ((mdl.F && !d_num) || (mdl.M && !d_cat) || (rows && !out_f && !out_i))
@@ -2472,7 +2513,7 @@ static cofactor_status predict_device(cofactor_ctx *ctx, const PredictModel &mdl
     const int32_t *kb = d_i, *keys = d_i + mdl.kbegin.size(), *labels = keys + mdl.keys.size();
     e = launch_predict(argmax, nc, cc, mdl.F, mdl.M, mdl.C, mdl.KT, kb, keys, d_w, d_mask, rows,
                        out_f, out_i, (argmax && emit_label) ? labels : nullptr, noise ? 1 : 0,
-                       mdl.noise_sd, seed, ctx->cus * 8, lds_limit, ctx->stream);
+                       mdl.noise_sd, seed, ctx->cus * 8, lds_limit, ctx->stream, d_row_ids);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_i); (void)hipFree(d_w);
@@ -2492,6 +2533,20 @@ cofactor_status cofactor_linreg_predict_device(cofactor_ctx *ctx, const float *p
   if (!linreg_model(params, n_params, n_num, n_cat, noise != 0, normalize != 0, mdl, err))
     return fail(COFACTOR_ERR_INVALID, err);
   return predict_device(ctx, mdl, false, false, noise != 0, seed, d_num, d_cat, d_mask, rows, d_out, nullptr);
+}
+
+cofactor_status cofactor_linreg_predict_rows_device(cofactor_ctx *ctx, const float *params, uint64_t n_params,
+                                                    int32_t noise, int32_t normalize, uint64_t seed,
+                                                    const float *const *d_num, int32_t n_num,
+                                                    const int32_t *const *d_cat, int32_t n_cat,
+                                                    const uint8_t *d_mask, const uint32_t *d_row_ids, uint64_t rows,
+                                                    float *d_out) {
+  if (!ctx || !params || n_num < 0 || n_cat < 0) return fail(COFACTOR_ERR_INVALID, "null argument");
+  PredictModel mdl;
+  std::string err;
+  if (!linreg_model(params, n_params, n_num, n_cat, noise != 0, normalize != 0, mdl, err))
+    return fail(COFACTOR_ERR_INVALID, err);
+  return predict_device(ctx, mdl, false, false, noise != 0, seed, d_num, d_cat, d_mask, rows, d_out, nullptr, d_row_ids);
 }
 
 cofactor_status cofactor_lda_predict_device(cofactor_ctx *ctx, const float *params,

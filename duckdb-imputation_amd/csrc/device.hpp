@@ -316,6 +316,7 @@ hipError_t launch_predict(bool argmax, const NumCols &num, const CatCols &cat, i
                           int KT, const int32_t *kbegin, const int32_t *keys, const double *W,
                           const uint8_t *mask, uint64_t rows, float *out_f, int32_t *out_i,
                           const int32_t *labels, int noise, double noise_sd,
-                          unsigned long long seed, int grid, size_t lds_limit, hipStream_t stream);
+                          unsigned long long seed, int grid, size_t lds_limit, hipStream_t stream,
+                          const uint32_t *row_ids = nullptr);
 
 }  // namespace cofactor

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(PREDICT_THREADS) void predict_kernel(
     const int32_t *__restrict__ keys, const double *__restrict__ W, int w_in_lds,
     const uint8_t *__restrict__ mask, uint64_t rows, float *__restrict__ out_f,
     int32_t *__restrict__ out_i, const int32_t *__restrict__ labels, int noise, double noise_sd,
-    unsigned long long seed) {
+    unsigned long long seed, const uint32_t *__restrict__ row_ids) {
   extern __shared__ double smem[];
   // LDS: [W (C * P doubles) if it fits][keys KT][kbegin M+1][x tile F x 256][slot tile M x 256]
   //      [per wave: queue of selected rows, QCAP u32]
@@ -83,7 +83,9 @@ __global__ __launch_bounds__(PREDICT_THREADS) void predict_kernel(
       out_i[row] = labels ? labels[arg] : arg;
     } else {
       if (noise) {
-        const unsigned long long h = mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1));
+        // (row_ids: the rows have been reordered — a row keeps the draw of its original place)
+        const unsigned long long rid = row_ids ? (unsigned long long)row_ids[row] : (unsigned long long)row;
+        const unsigned long long h = mix64(seed + 0x9E3779B97F4A7C15ull * (rid + 1));
         const double u1 = ((double)(h >> 32) + 1.0) * (1.0 / 4294967296.0);  // (0, 1]
         const double u2 = (double)(h & 0xFFFFFFFFull) * (1.0 / 4294967296.0);
         best += noise_sd * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
@@ -138,7 +140,8 @@ hipError_t launch_predict(bool argmax, const NumCols &num, const CatCols &cat, i
                           int KT, const int32_t *kbegin, const int32_t *keys, const double *W,
                           const uint8_t *mask, uint64_t rows, float *out_f, int32_t *out_i,
                           const int32_t *labels, int noise, double noise_sd,
-                          unsigned long long seed, int grid, size_t lds_limit, hipStream_t stream) {
+                          unsigned long long seed, int grid, size_t lds_limit, hipStream_t stream,
+                          const uint32_t *row_ids) {
   if (rows == 0) return hipSuccess;
   int w_in_lds = 0;
   const size_t lds = predict_lds_bytes(F, M, C, KT, lds_limit, &w_in_lds);
@@ -152,14 +155,14 @@ hipError_t launch_predict(bool argmax, const NumCols &num, const CatCols &cat, i
     if (e != hipSuccess) return e;
     predict_kernel<true><<<grid, PREDICT_THREADS, lds, stream>>>(
         num, cat, F, M, C, KT, kbegin, keys, W, w_in_lds, mask, rows, out_f, out_i, labels, noise,
-        noise_sd, seed);
+        noise_sd, seed, row_ids);
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&predict_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     predict_kernel<false><<<grid, PREDICT_THREADS, lds, stream>>>(
         num, cat, F, M, C, KT, kbegin, keys, W, w_in_lds, mask, rows, out_f, out_i, labels, noise,
-        noise_sd, seed);
+        noise_sd, seed, row_ids);
   }
   return hipGetLastError();
 }

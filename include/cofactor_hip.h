@@ -460,6 +460,18 @@ cofactor_status cofactor_linreg_predict_device(cofactor_ctx *ctx, const float *p
                                                const int32_t *const *d_cat, int32_t n_cat,
                                                const uint8_t *d_mask, uint64_t rows, float *d_out);
 
+/* The same over rows that have been REORDERED (a table partitioned by its null pattern,
+ * imputation/algorithms/imputation_low.cpp): d_row_ids[i] (optional) is the index row i had in the
+ * original table — it draws the noise of that place, hash(seed + 0x9E3779B97F4A7C15 * (d_row_ids[i] + 1)),
+ * so the imputed values do not depend on the reordering. */
+cofactor_status cofactor_linreg_predict_rows_device(cofactor_ctx *ctx, const float *params,
+                                                    uint64_t n_params, int32_t noise,
+                                                    int32_t normalize, uint64_t seed,
+                                                    const float *const *d_num, int32_t n_num,
+                                                    const int32_t *const *d_cat, int32_t n_cat,
+                                                    const uint8_t *d_mask, const uint32_t *d_row_ids,
+                                                    uint64_t rows, float *d_out);
+
 /* lda_predict — LDA_impute (lda.cpp:421-590): argmax over classes of intercept + coef . [x,
  * onehot].  d_cat[n_cat] are the key columns in training order WITHOUT the label.  The reference
  * returns the class INDEX (lda.cpp:560); emit_label != 0 writes the class key instead, which is

@@ -84,6 +84,43 @@ def test_mice_iteration_improves_on_the_baseline_fill():
     ctx.close()
 
 
+def test_partitioned_mice_equals_the_filtered_run():
+    """run_mice_partitioned (rows reordered by null pattern, triple(present rows) = triple(all) -
+    triple(missing rows), two aggregates over the missing rows per column) against run_mice (one
+    filtered aggregate over the whole table per column): the same models to the rounding of a blob
+    subtraction, the same numeric fills (each row draws the noise of its original place), the same
+    key fills; present values untouched; the ranges cover exactly the missing rows."""
+    import torch
+    rows = 300_007
+    ta, truth = _table(rows, seed=9)
+    tb, _ = _table(rows, seed=9)
+    ctx = cofactor_hip.Context(0)
+    mice.init_baseline(ctx, ta)
+    mice.init_baseline(ctx, tb)
+    ma = mice.run_mice(ctx, ta, iterations=2, seed=5, skip_init=True)
+    log = {}
+    mb, pt = mice.run_mice_partitioned(ctx, tb, iterations=2, seed=5, skip_init=True, timings=log)
+    for name, null in (("k0", truth["k0_null"]), ("x0", truth["x0_null"])):
+        covered = np.zeros(rows, bool)
+        order = pt.order.cpu().numpy()
+        for a, b in pt.ranges[name]:
+            covered[order[a:b]] = True
+        assert np.array_equal(covered, null), name
+    assert len(pt.ranges["k0"]) <= 2 and len(pt.ranges["x0"]) <= 2
+    pt.write_back()
+    for name in ("x0", "k0"):
+        assert np.allclose(ma[name], mb[name], rtol=1e-4, atol=1e-5), (name, np.abs(ma[name] - mb[name]).max())
+    xa, xb = ta.num["x0"].cpu().numpy(), tb.num["x0"].cpu().numpy()
+    ka, kb = ta.cat["k0"].cpu().numpy(), tb.cat["k0"].cpu().numpy()
+    xn, kn = truth["x0_null"], truth["k0_null"]
+    assert np.array_equal(xb[~xn], truth["x0"][~xn]) and np.array_equal(kb[~kn], truth["k0"][~kn])
+    assert np.mean(ka == kb) > 0.9995                  # (an argmax within rounding of a tie may flip)
+    same_keys = ka == kb
+    assert np.allclose(xa[same_keys], xb[same_keys], rtol=1e-3, atol=2e-3)
+    assert all(v > 0 for v in log.values())
+    ctx.close()
+
+
 def test_mice_through_the_rccl_path_matches_the_single_process_run():
     """The sharded loop exchanges only the all-reduced triple per column.  On a one-GPU box the
     RCCL process group has one rank: the run goes through export -> all-reduce -> import and the
