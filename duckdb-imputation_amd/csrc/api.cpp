@@ -1326,6 +1326,7 @@ void cofactor_ctx_destroy(cofactor_ctx *ctx) {
   (void)hipFree(ctx->ring_red);
   (void)hipFree(ctx->ring_scratch);
   (void)hipFree(ctx->seg_scratch);
+  (void)hipFree(ctx->predict_buf);
   (void)hipFree(ctx->code_cache);
   (void)hipFree(ctx->pair_tmp);
   (void)hipFree(ctx->fin_dev);
@@ -2472,8 +2473,7 @@ cofactor_status cofactor_lda_train(const double *triple, uint64_t triple_len, in
   return emit_floats(params, out, cap, needed);
 }
 
-// uploads the model, runs the kernel on the context stream and waits for it (the model buffers
-// are freed on return)
+// uploads the model, runs the kernel on the context stream and waits for it
 static cofactor_status predict_device(cofactor_ctx *ctx, const PredictModel &mdl, bool argmax,
                                       bool emit_label, bool noise, uint64_t seed,
                                       const float *const *d_num, const int32_t *const *d_cat,
@@ -2500,14 +2500,19 @@ static cofactor_status predict_device(cofactor_ctx *ctx, const PredictModel &mdl
   if (predict_lds_bytes(mdl.F, mdl.M, mdl.C, mdl.KT, lds_limit, &w_in_lds) > lds_limit)
     return fail(COFACTOR_ERR_UNSUPPORTED, "predict: the key dictionaries of the model exceed the LDS budget");
   const size_t nk = mdl.kbegin.size() + mdl.keys.size() + mdl.labels.size();
-  int32_t *d_i = nullptr;
-  double *d_w = nullptr;
   std::vector<int32_t> hi(mdl.kbegin);
   hi.insert(hi.end(), mdl.keys.begin(), mdl.keys.end());
   hi.insert(hi.end(), mdl.labels.begin(), mdl.labels.end());
-  HIP_TRY(hipMalloc((void **)&d_i, sizeof(int32_t) * nk));
-  hipError_t e = hipMalloc((void **)&d_w, sizeof(double) * mdl.W.size());
-  if (e == hipSuccess) e = hipMemcpyAsync(d_i, hi.data(), sizeof(int32_t) * nk, hipMemcpyHostToDevice, ctx->stream);
+  // the model's device copy lives in a context buffer (a MICE loop predicts several row ranges per
+  // column: an allocation and a free per call cost more than the kernel on 1e7 rows)
+  const size_t w_off = (sizeof(int32_t) * nk + 255) & ~(size_t)255;
+  {
+    cofactor_status rs = scratch_reserve(ctx, ctx->predict_buf, ctx->predict_bytes, w_off + sizeof(double) * mdl.W.size() + 256);
+    if (rs != COFACTOR_OK) return rs;
+  }
+  int32_t *d_i = reinterpret_cast<int32_t *>(ctx->predict_buf);
+  double *d_w = reinterpret_cast<double *>(ctx->predict_buf + w_off);
+  hipError_t e = hipMemcpyAsync(d_i, hi.data(), sizeof(int32_t) * nk, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_w, mdl.W.data(), sizeof(double) * mdl.W.size(), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     const int32_t *kb = d_i, *keys = d_i + mdl.kbegin.size(), *labels = keys + mdl.keys.size();
@@ -2515,8 +2520,7 @@ static cofactor_status predict_device(cofactor_ctx *ctx, const PredictModel &mdl
                        out_f, out_i, (argmax && emit_label) ? labels : nullptr, noise ? 1 : 0,
                        mdl.noise_sd, seed, ctx->cus * 8, lds_limit, ctx->stream, d_row_ids);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_i); (void)hipFree(d_w);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (`hi` and the model are the caller's / this frame's)
   if (e != hipSuccess) return fail(COFACTOR_ERR_HIP, hipGetErrorString(e));
   return COFACTOR_OK;
 }

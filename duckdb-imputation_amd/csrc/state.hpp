@@ -54,6 +54,8 @@ struct cofactor_ctx {
   size_t skip_bytes = 0;
   size_t lds_max = 160 * 1024;  // LDS one workgroup may claim on this device
   double *ring_red = nullptr;   // 256 doubles: reduced dense children of a vector of triples (sum_triple)
+  unsigned char *predict_buf = nullptr;   // the model of a predict call on the device (keys, labels, weights), grown on demand
+  size_t predict_bytes = 0;
   void *seg_scratch = nullptr;  // segmented GROUP BY (groupseg.hip): codes, offsets, regrouped records (grown on demand)
   size_t seg_scratch_bytes = 0;
   int groups_seg = 0;           // COFACTOR_GROUPS_SEG=1: segmented path whenever the shape allows, =2: never; default by size
