@@ -139,10 +139,13 @@ __global__ __launch_bounds__(TW) void seg_scatter_kernel(const int32_t *__restri
                                                              int groups, unsigned *__restrict__ cur, float *__restrict__ rec) {
   extern __shared__ __attribute__((aligned(16))) unsigned l_raw[];
   constexpr int R4 = RS / 4, RPI = 64 / R4, NIT = (64 + RPI - 1) / RPI;
-  constexpr int WSTRIDE = 64 * RS + 64;                // words of one wave's staging: records, then their places
+  // a parked record takes RS + 4 words: with a stride of RS (a multiple of 32 words at 20_0) the 16-byte
+  // writes of a wave's lanes all fall on two bank groups (SQ_LDS_BANK_CONFLICT: 7.1e8 cycles per 1e8 rows)
+  constexpr int RSP = RS + 4;
+  constexpr int WSTRIDE = 64 * RSP + 64;               // words of one wave's staging: records, then their places
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float *l_rec = reinterpret_cast<float *>(l_raw) + (size_t)wave * WSTRIDE;
-  unsigned *l_pos = l_raw + (size_t)wave * WSTRIDE + 64 * RS;
+  unsigned *l_pos = l_raw + (size_t)wave * WSTRIDE + 64 * RSP;
   unsigned *l_cur = l_raw + (size_t)(TW / 64) * WSTRIDE;
   uint64_t lo, hi, stride;
   if (LDSCUR) {
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(TW) void seg_scatter_kernel(const int32_t *__restri
     l_pos[lane] = pos;
 #pragma unroll
     for (int q = 0; q < R4; q++)
-      *reinterpret_cast<f32x4 *>(l_rec + lane * RS + 4 * q) = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+      *reinterpret_cast<f32x4 *>(l_rec + lane * RSP + 4 * q) = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(TW) void seg_scatter_kernel(const int32_t *__restri
       if (sub < RPI && rr < 64) {
         const unsigned p = l_pos[rr];
         if (p != 0xFFFFFFFFu)
-          *reinterpret_cast<f32x4 *>(rec + (size_t)p * RS + 4 * piece) = *reinterpret_cast<const f32x4 *>(l_rec + rr * RS + 4 * piece);
+          *reinterpret_cast<f32x4 *>(rec + (size_t)p * RS + 4 * piece) = *reinterpret_cast<const f32x4 *>(l_rec + rr * RSP + 4 * piece);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -333,7 +336,7 @@ hipError_t launch_groups_segmented(const int32_t *gid, const NumCols &num, int n
 #define SEG_CASE(R, GK)                                                                                               \
   case R: {                                                                                                           \
     constexpr int TW = R > 16 ? 512 : SEG_WG;        /* staged records + 12288 cursors within 160 KB of LDS */      \
-    const size_t stage = (size_t)(TW / 64) * (64 * R + 64) * 4;                                                       \
+    const size_t stage = (size_t)(TW / 64) * (64 * (R + 4) + 64) * 4;                                                 \
     if (lds) {                                                                                                        \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(seg_scatter_kernel<R, true, TW>),             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
